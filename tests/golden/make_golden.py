@@ -1,0 +1,177 @@
+"""Generate the golden vectors in tests/golden/*.npz by running the REAL reference on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The fixtures are data: seeded inputs (or their SHA-256 when they are regenerated deterministically by
+``streammos_amd.synth`` / ``streammos_amd.preprocess``) and the reference's outputs.  No reference
+source or bytecode is stored.  How the reference is made importable on CPU: oracle/ref_import.py.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def gen_voxel_maxpool(ns, out):
+    for name, (feat, ind, out_size, scale) in cases.voxel_maxpool_cases().items():
+        f = torch.from_numpy(feat).unsqueeze(-1).requires_grad_(True)
+        i = torch.from_numpy(ind).unsqueeze(-1)
+        y = ns.deep_point.VoxelMaxPool(f, i, tuple(out_size), tuple(scale))
+        g = torch.from_numpy(cases.grad_like(y.shape, name))
+        y.backward(g)
+        out["vmp_%s_in_sha" % name] = np.array(sha(feat, ind))
+        out["vmp_%s_out" % name] = y.detach().numpy()
+        out["vmp_%s_grad" % name] = f.grad[..., 0].numpy()
+
+
+def gen_bilinear(ns, out):
+    for name, (grid, coord, scale) in cases.bilinear_cases().items():
+        mod = ns.backbone.BilinearSample(in_dim=grid.shape[1], scale_rate=scale)
+        y = mod(torch.from_numpy(grid), torch.from_numpy(coord).unsqueeze(-1))
+        out["bil_%s_in_sha" % name] = np.array(sha(grid, coord))
+        out["bil_%s_out" % name] = y[..., 0].numpy()
+
+
+def gen_msda(ns, out):
+    core = ns.msda_func.ms_deform_attn_core_pytorch
+    for name, (value, shapes, lsi, loc, attn) in cases.msda_cases().items():
+        y64 = core(torch.from_numpy(value).double(), torch.from_numpy(shapes),
+                   torch.from_numpy(loc).double(), torch.from_numpy(attn).double())
+        y32 = core(torch.from_numpy(value), torch.from_numpy(shapes),
+                   torch.from_numpy(loc), torch.from_numpy(attn))
+        out["msda_%s_in_sha" % name] = np.array(sha(value, shapes, lsi, loc, attn))
+        out["msda_%s_out64" % name] = y64.numpy()
+        out["msda_%s_out32" % name] = y32.numpy()
+    # module-level: MSDeformAttn.forward with seeded weights (deformattn/modules/ms_deform_attn.py:78-116)
+    from streammos_amd import synth
+    mod = ns.msda_modules.MSDeformAttn(d_model=128, n_levels=1, n_heads=4, n_points=4).eval()
+    sd = synth.seeded_state_dict({("cross_attn." + k): v for k, v in mod.state_dict().items()})
+    mod.load_state_dict({k[len("cross_attn."):]: v for k, v in sd.items()})
+    q, ref, src, shapes, lsi = cases.msda_module_case()
+    with torch.no_grad():
+        y = mod(torch.from_numpy(q), torch.from_numpy(ref), torch.from_numpy(src),
+                torch.from_numpy(shapes), torch.from_numpy(lsi))
+    out["msda_module_in_sha"] = np.array(sha(q, ref, src))
+    out["msda_module_out"] = y.numpy()
+
+
+def gen_voting(ns, out):
+    crop = ns.transforms.Crop(dims=(0, 1, 2), fov=[[-50, -50, -4], [50, 50, 2]])
+    v = ns.voting
+    size = (512, 512, 30)
+    for name, (cur, cur_pred, hist, hist_pred) in cases.voting_cases().items():
+        h_pts, h_lab, h_mask = crop(torch.tensor(hist), torch.tensor(hist_pred.astype("uint8")))
+        c_pts, c_lab, c_mask = crop(torch.tensor(cur), torch.tensor(cur_pred.astype("uint8")))
+        n_hist = len(h_pts)
+        pts = torch.cat((h_pts, c_pts), 0)
+        lab = torch.cat((h_lab, c_lab), 0)
+        quan = v.Quantize(pts, range_x=(-50.0, 50.0), range_y=(-50.0, 50.0), range_z=(-4.0, 2.0), size=size)
+        vox = v.determine_voxel_labels(quan.to(torch.int64), lab.to(torch.int64), size)
+        new = v.get_point_labels_from_voxel_labels(quan[n_hist:].to(torch.int64), vox, size)
+        refined = cur_pred.copy()
+        refined[c_mask.numpy()] = new.numpy()
+        nz = torch.nonzero(vox.reshape(-1)).reshape(-1)
+        out["vote_%s_in_sha" % name] = np.array(sha(cur, cur_pred, hist, hist_pred))
+        out["vote_%s_cur_mask" % name] = c_mask.numpy()
+        out["vote_%s_hist_mask" % name] = h_mask.numpy()
+        out["vote_%s_coords" % name] = quan.to(torch.int64).numpy().astype(np.int32)
+        out["vote_%s_voxel_nz_idx" % name] = nz.numpy()
+        out["vote_%s_voxel_nz_val" % name] = vox.reshape(-1)[nz].numpy().astype(np.int8)
+        out["vote_%s_refined" % name] = refined.astype(np.int8)
+        lut = v.map(refined.astype(np.int64), {0: 0, 1: 9, 2: 251})
+        out["vote_%s_lut" % name] = lut.astype(np.int32)
+
+
+def gen_preprocess(out):
+    """datasets/utils.py is loaded by path (the package __init__ drags in the whole dataset module);
+    make_point_feat (datasets/data_StreamMOS.py:25-50) is pulled out of the source text."""
+    import ast
+    import types
+    spec = importlib.util.spec_from_file_location(
+        "smos_ref_dataset_utils", os.path.join(ref_import.REF_ROOT, "datasets", "utils.py"))
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    path = os.path.join(ref_import.REF_ROOT, "datasets", "data_StreamMOS.py")
+    tree = ast.parse(open(path).read(), path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "make_point_feat"]
+    mod = types.ModuleType("smos_ref_make_point_feat")
+    mod.__dict__.update(np=np)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), mod.__dict__)
+
+    class Voxel:
+        RV_theta = (-25.0, 3.0)
+        range_x = (-50.0, 50.0)
+        range_y = (-50.0, 50.0)
+        range_z = (-4.0, 2.0)
+        bev_shape = (512, 512, 30)
+        rv_shape = (64, 2048)
+
+    scan, pose_diff = cases.preprocess_case()
+    moved = du.Trans(scan, pose_diff)
+    mask = du.filter_pcds_mask(moved, range_x=Voxel.range_x, range_y=Voxel.range_y, range_z=Voxel.range_z)
+    kept = moved[mask]
+    coord = du.Quantize(kept, range_x=Voxel.range_x, range_y=Voxel.range_y, range_z=Voxel.range_z,
+                        size=Voxel.bev_shape)
+    sph = du.SphereQuantize(kept, phi_range=(-180.0, 180.0), theta_range=Voxel.RV_theta, size=Voxel.rv_shape)
+    feat = mod.make_point_feat(kept, coord, sph, Voxel)
+    out["pre_in_sha"] = np.array(sha(scan, pose_diff))
+    out["pre_moved"] = moved
+    out["pre_mask"] = mask
+    out["pre_coord"] = coord.astype(np.float32)
+    out["pre_sphere"] = sph.astype(np.float32)
+    out["pre_feat"] = feat.astype(np.float32)
+    out["pre_dtypes"] = np.array([str(coord.dtype), str(sph.dtype), str(feat.dtype)])
+
+
+def gen_e2e(ns, out):
+    from streammos_amd import synth
+    model = ns.StreamMOS.AttNet(ns.config.get_config()[2]).eval()
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    memory = None
+    for i, batch in enumerate(cases.e2e_frames()):
+        tb = {k: torch.from_numpy(v).unsqueeze(0) for k, v in batch.items()}
+        with torch.no_grad():
+            pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+        out["e2e_f%d_in_sha" % i] = np.array(sha(batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"]))
+        out["e2e_f%d_pred" % i] = pred.numpy()
+        out["e2e_f%d_mem_sub" % i] = memory[:, ::8, ::4, ::4].contiguous().numpy()
+        out["e2e_f%d_mem_stats" % i] = np.array([memory.double().sum().item(), memory.double().abs().sum().item()])
+        out["e2e_f%d_aux_sub" % i] = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].contiguous().numpy()
+
+
+def main():
+    ns = ref_import.import_reference()
+    torch.set_num_threads(8)
+    for name, fn, needs_ns in (("ops_voxel_maxpool", gen_voxel_maxpool, True), ("ops_bilinear", gen_bilinear, True),
+                               ("ops_msda", gen_msda, True), ("ops_voting", gen_voting, True),
+                               ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True)):
+        out = {}
+        fn(ns, out) if needs_ns else fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-20s %4d arrays %8.1f KiB" % (name, len(out), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
