@@ -1,0 +1,194 @@
+"""bench.py -- LiDAR scans/s of the full StreamMOS streaming-inference step on MI355X.
+
+One "step" = one streamed scan through the whole hot path with its inputs already resident in HBM:
+AttNet.infer at the reference's validation shape (B = 4 TTA variants, T = 3 stacked scans, N = 160 000
+padded points, fp32) -> TTA softmax/mean/argmax -> scatter to the raw scan -> 8-frame voxel voting.
+Workload = BASELINE.json configs[1] on synthetic 120k-point scans (no SemanticKITTI offline).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched under torch.distributed.run, one rank per GPU, each rank streams its OWN sequence
+(sequence sharding, no collective on the data path) -> "scaling": "weak".
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_GB_PER_SCAN = 11.2           # 2.806 GB/sample x 4 TTA samples
+FRAME_POINT_NUM = 160000         # config/StreamMOS.py:44 (Val.frame_point_num)
+
+
+def algorithmic_bytes(label):
+    """Bytes a kernel launch must move if every operand is touched exactly once (float32)."""
+    name, dims = label.split("[", 1)
+    dims = dims.rstrip("]")
+    if name == "voxel_maxpool_fwd":
+        src, dst = dims.split("->")
+        bs, c, n = (int(v) for v in src.split("x"))
+        cells = int(np.prod([int(v) for v in dst.split("x")]))
+        d = len(dst.split("x"))
+        return 4 * (bs * c * n + bs * n * d + bs * c * cells)
+    if name == "bilinear_gather":
+        src, n = dims.split("->")
+        b, c, h, w = (int(v) for v in src.split("x"))
+        n = int(n)
+        return 4 * (b * c * h * w + b * n * 2 + b * c * n)
+    if name == "msda_fwd":
+        n, lq, m, d = (int(v) for v in dims.split("x"))
+        return 4 * (n * lq * m * d * 2 + n * lq * m * 4 * 3)
+    return 0
+
+
+def make_frames(n_frames, seq_seed, tta=True):
+    """Host preprocessing of a synthetic sequence -> list of (sample, raw_scan, pose)."""
+    from streammos_amd import preprocess, synth
+    spec = preprocess.VoxelSpec()
+    total = n_frames + 2
+    base = seq_seed * 1000
+    scans = [synth.synthetic_scan(base + k) for k in range(total)]
+    poses = [synth.synthetic_pose(k) for k in range(total)]
+    out = []
+    for i in range(n_frames):
+        idx = preprocess.window_indices(i, total, 3)
+        s = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], FRAME_POINT_NUM, spec, tta=tta)
+        out.append((s, scans[i], poses[i]))
+    return out
+
+
+def cpu_baseline(frames, state_dict, n_timed):
+    """The CPU restatement of the same path (oracle/, bit-/tolerance-pinned to the reference) on the host
+    cores of this box: 1 warm-up + n_timed scans at the same shape."""
+    from oracle import net_torch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    net = net_torch.OracleNet(state_dict)
+    memory = None
+    t0 = None
+    for i in range(n_timed + 1):
+        s = frames[i % len(frames)][0]
+        if i == 1:
+            t0 = time.perf_counter()
+        pred, _, _, _, memory = net.stage_forward(*(torch.from_numpy(s[k]) for k in
+                                                    ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), memory)
+        net_torch.tta_labels(pred)
+    dt = time.perf_counter() - t0
+    return {"value": n_timed / dt, "unit": "scans/s", "cores": cores, "kind": "port",
+            "sample": "%d warm-up + %d timed scans, B=4 TTA x T=3 x N=%d, torch-CPU fp32 restatement "
+                      "(forward + TTA argmax, voting excluded)" % (1, n_timed, FRAME_POINT_NUM)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=10, help="distinct preprocessed scans cycled through")
+    ap.add_argument("--no-vote", action="store_true")
+    ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from streammos_amd import profiling, streaming, synth
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    state = synth.seeded_state_dict(model.state_dict())
+    model.load_state_dict(state, strict=True)
+    runner = streaming.StreamRunner(model, device, vote=not args.no_vote)
+
+    frames = make_frames(args.frames, seq_seed=rank)
+    dev_frames = [(runner.upload(s, raw), pose) for s, raw, pose in frames]
+
+    def one_step(i):
+        d, pose = dev_frames[i % len(dev_frames)]
+        return runner.step(d, pose)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warm-up: also finds the dominant hand-written kernel
+    with profiling.kernel_timer() as kt:
+        for i in range(args.warmup):
+            one_step(i)
+    warm = kt.summary()
+    dominant = max(warm, key=lambda k: warm[k][1]) if warm else None
+
+    sync()
+    t0 = time.perf_counter()
+    with profiling.kernel_timer(only=dominant) as kt:
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+    timed = kt.summary()
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        roof = None
+        if dominant and dominant in timed:
+            calls, total_ms, mean_ms = timed[dominant]
+            ab = algorithmic_bytes(dominant)
+            achieved = ab / (mean_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(mean_ms, 4), "launches": calls}
+        line = {
+            "metric": "LiDAR scans/sec (StreamMOS streaming inference + voxel voting)",
+            "value": round(value, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: full StreamMOS streaming inference, 1 sequence per GPU, B=4 TTA x T=3 "
+                                   "x N=160000 padded points (120k-point synthetic HDL-64E scans), 8-frame voxel "
+                                   "voting %s" % ("off" if args.no_vote else "on"),
+                       "tta": 4, "frame_point_num": FRAME_POINT_NUM, "parallelism": "sequence-shard x%d" % world},
+            "roofline": roof,
+            "path_roofline": {"bound": "hbm", "achieved": round(value / world * ALG_GB_PER_SCAN, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(value / world * ALG_GB_PER_SCAN / HBM_PEAK_GBS, 4),
+                              "note": "scans/s/GPU x 11.2 GB algorithmic bytes per scan (SURVEY.md 8d)"},
+            "hip_kernel_ms_per_step": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
+        }
+        if world == 1 and args.cpu_scans > 0:
+            line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/*
+ * smos.h -- C ABI of libsmos_hip.so: the MI355X (gfx950) kernels of the StreamMOS
+ * streaming-inference path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no torch types.  Every entry point
+ *   - takes DEVICE pointers for tensors (HBM resident), HOST pointers for small shape/stride/scale
+ *     vectors unless the comment says "device",
+ *   - launches asynchronously on the hipStream_t passed as `stream` (never on the legacy default
+ *     stream, unlike the reference's deep_point launches, point_deep_cuda_kernel.cu:153-160),
+ *   - allocates nothing, synchronises nothing, keeps no global state (graph-capturable),
+ *   - returns SMOS_OK or an error code; smos_last_error() gives the thread-local message that the
+ *     Python shims turn into RuntimeError (the reference raises c10::Error -> RuntimeError,
+ *     point_deep_cuda.cpp:11-13).
+ *
+ * Each function names the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef SMOS_H_
+#define SMOS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMOS_ABI_VERSION 1
+
+enum smos_status {
+  SMOS_OK = 0,
+  SMOS_ERR_ARG = 1,          /* null pointer, bad size, unsupported rank */
+  SMOS_ERR_UNSUPPORTED = 2,  /* dtype / shape outside what this build implements */
+  SMOS_ERR_LAUNCH = 3        /* the HIP runtime reported a launch error */
+};
+
+enum smos_dtype { SMOS_F32 = 0, SMOS_F16 = 1, SMOS_F64 = 2 };
+
+typedef void* smos_stream_t; /* hipStream_t */
+
+int smos_abi_version(void);
+const char* smos_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Point -> grid max-pool scatter.
+ * Replaces point_deep.cuda_kernel.voxel_maxpooling_forward (deep_point/src/point_deep_cuda.cpp:20-37,
+ * kernels deep_point/src/point_deep_cuda_kernel.cu:24-99) -- three launches, an int64 index scratch
+ * and CAS-loop float atomics there; one fused launch with native integer atomic max here.
+ *
+ *   feat   [BS, C, N]      element strides feat_stride[3] (reference layout: {C*N, N, 1})
+ *   ind    [BS, N, D]      contiguous, same dtype as feat; D <= 4
+ *   out    [BS, C, D1..Dn] element strides out_stride[2+D]; MUST be zero-filled by the caller
+ *                          (the reference's caller does so, deep_point/__init__.py:26)
+ *   voxel_max_idx [BS, N]  int64, pre-filled with -1 by the caller, or NULL to skip it; receives
+ *                          bs*out_stride[0] + sum_d cell_d*out_stride[2+d] for kept points
+ *   out_size[D], scale[D]  host
+ *   flag_ws                device int32 scratch (4 bytes); used to detect negative features, which take
+ *                          a slower exact path (see DESIGN.md "VoxelMaxPool")
+ * cell_d = (int64)((float)ind_d * scale_d) truncated toward zero; a point is kept iff every
+ * 0 <= cell_d < out_size[d].  Occupied cell = max over its members; empty cell stays 0.
+ */
+int smos_voxel_maxpool_fwd(const void* feat, const int64_t* feat_stride, const void* ind, void* out,
+                           const int64_t* out_stride, int64_t* voxel_max_idx, int64_t BS, int64_t C,
+                           int64_t N, int32_t D, const int64_t* out_size, const float* scale,
+                           int32_t dtype, int32_t* flag_ws, smos_stream_t stream);
+
+/* Replaces point_deep.cuda_kernel.voxel_maxpooling_backward (point_deep_cuda.cpp:39-57, kernel
+ * point_deep_cuda_kernel.cu:109-132): grad_feat[b,c,n] = grad_out[cell] iff out[cell] == feat[b,c,n].
+ * grad_feat must be zero-filled by the caller; grad_out uses out's strides. */
+int smos_voxel_maxpool_bwd(const void* feat, const int64_t* feat_stride, const void* ind, const void* out,
+                           const void* grad_out, const int64_t* out_stride, void* grad_feat, int64_t BS,
+                           int64_t C, int64_t N, int32_t D, const int64_t* out_size, const float* scale,
+                           int32_t dtype, smos_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Grid -> point bilinear gather.
+ * Replaces networks/backbone.py:453-475 (BilinearSample = F.grid_sample, bilinear, zeros padding,
+ * align_corners=True) including its float32 normalise / un-normalise round trip.
+ *   grid  [B, C, H, W]  element strides grid_stride[4]  (NCHW or NHWC both fine)
+ *   coord [B, N, K]     contiguous, K >= 2; row = coord[...,0]*scale[0], col = coord[...,1]*scale[1]
+ *   out   [B, C, N]     element strides out_stride[3]
+ */
+int smos_bilinear_gather_fwd(const float* grid, const int64_t* grid_stride, const float* coord, int32_t K,
+                             float* out, const int64_t* out_stride, int64_t B, int64_t C, int64_t H,
+                             int64_t W, int64_t N, const float* scale, smos_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention sampler, forward.
+ * Replaces MultiScaleDeformableAttention.ms_deform_attn_forward (deformattn/src/vision.cpp:13-16 ->
+ * deformattn/src/cuda/ms_deform_attn_cuda.cu:20-80, kernel ms_deform_im2col_cuda.cuh:237-299).
+ *   value [N, S, M, D]; spatial_shapes [L,2] int64 DEVICE; level_start_index [L] int64 DEVICE
+ *   sampling_loc [N, Lq, M, L, P, 2]; attn_weight [N, Lq, M, L, P]; out [N, Lq, M*D]  (all contiguous)
+ * dtype: SMOS_F32 or SMOS_F64 (the reference dispatches float/double only, ms_deform_attn_cuda.cu:64).
+ */
+int smos_msda_fwd(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                  const void* sampling_loc, const void* attn_weight, void* out, int64_t N, int64_t S,
+                  int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P, int32_t dtype,
+                  smos_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * TTA reduce: softmax over classes, mean over the B test-time-augmentation variants, argmax.
+ * Replaces val_StreamMOS.py:97-98,113.  pred [B, K, N] float32 contiguous (K <= 8) -> labels [N] uint8,
+ * prob [N, K] float32 (optional, may be NULL).
+ */
+int smos_tta_argmax(const float* pred, int64_t B, int64_t K, int64_t N, uint8_t* labels, float* prob,
+                    smos_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Voxel voting (voxel_voting.py:38-91,214-242).  The vote table is a dense array of
+ * SMOS_VOTE_CELLS packed 64-bit words (three 21-bit class counters per voxel) that stays in HBM;
+ * the caller zero-fills it per frame (smos_vote_clear), accumulates the 8 history frames and the
+ * current frame, then resolves the current frame's labels.
+ *
+ *   pts [n, pt_stride] float32 rows (x, y, z, ...) in the frame's OWN sensor coordinates
+ *   labels [n] uint8 in {0,1,2}
+ *   pose_diff: host, 16 doubles row-major = inv(P_cur) * P_frame, or NULL for the current frame;
+ *              applied in float64 then rounded to float32 (datasets/utils.py:116-126)
+ *   recip_quantize: 0 = float32 true division (numpy / torch-CPU behaviour, the pinned one),
+ *                   1 = multiply by the float32 reciprocal of the cell size (what torch's CUDA div by a
+ *                       Python scalar does in voxel_voting.py:86-88 when run on a GPU)
+ * Crop (utils/transforms.py:151-161) and Quantize (voxel_voting.py:77-91) are fused in.
+ */
+#define SMOS_VOTE_NX 512
+#define SMOS_VOTE_NY 512
+#define SMOS_VOTE_NZ 30
+#define SMOS_VOTE_CELLS (512LL * 512LL * 30LL)
+
+int smos_vote_clear(uint64_t* table, smos_stream_t stream);
+int smos_vote_accumulate(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels,
+                         const double* pose_diff, int32_t recip_quantize, uint64_t* table,
+                         smos_stream_t stream);
+/* out_labels[i] = argmax of the voxel of point i (ties -> lowest class) if the point survives the crop,
+ * else labels[i]; lut (device, 256 int32 entries, e.g. {0:0,1:9,2:251}) is applied when non-NULL. */
+int smos_vote_resolve(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels,
+                      int32_t recip_quantize, const uint64_t* table, const int32_t* lut,
+                      int32_t* out_labels, smos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOS_H_ */

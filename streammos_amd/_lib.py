@@ -1,0 +1,69 @@
+"""ctypes binding of libsmos_hip.so (the C ABI declared in include/smos.h).
+
+There is no CPU fallback behind these calls: if the library is missing or a kernel reports an
+error the caller gets a RuntimeError, exactly like the reference's extension modules.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsmos_hip.so")
+
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+i64 = ctypes.c_int64
+i32 = ctypes.c_int32
+
+# name -> argtypes, in the order of include/smos.h
+SIGNATURES = {
+    "smos_abi_version": [],
+    "smos_voxel_maxpool_fwd": [vp, c_i64p, vp, vp, c_i64p, vp, i64, i64, i64, i32, c_i64p, c_f32p, i32, vp, vp],
+    "smos_voxel_maxpool_bwd": [vp, c_i64p, vp, vp, vp, c_i64p, vp, i64, i64, i64, i32, c_i64p, c_f32p, i32, vp],
+    "smos_bilinear_gather_fwd": [vp, c_i64p, vp, i32, vp, c_i64p, i64, i64, i64, i64, i64, c_f32p, vp],
+    "smos_msda_fwd": [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp],
+    "smos_tta_argmax": [vp, i64, i64, i64, vp, vp, vp],
+    "smos_vote_clear": [vp, vp],
+    "smos_vote_accumulate": [vp, i64, i64, vp, c_f64p, i32, vp, vp],
+    "smos_vote_resolve": [vp, i64, i64, vp, i32, vp, vp, vp, vp],
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "streammos_amd: %s is missing -- the HIP kernels are not built. Run "
+            "`python -m streammos_amd.build` (or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.smos_last_error.argtypes = []
+    lib.smos_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().smos_last_error().decode(errors="replace")
+        raise RuntimeError("%s failed (smos status %d): %s" % (what, rc, msg))
+
+
+def i64_array(values):
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def f32_array(values):
+    return (ctypes.c_float * len(values))(*[float(v) for v in values])
+
+
+def f64_array(values):
+    return (ctypes.c_double * len(values))(*[float(v) for v in values])

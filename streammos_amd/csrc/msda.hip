@@ -1,0 +1,160 @@
+// Multi-scale deformable attention sampler (forward) for gfx950.
+// Replaces ms_deformable_im2col_gpu_kernel (deformattn/src/cuda/ms_deform_im2col_cuda.cuh:237-299) and
+// ms_deform_attn_im2col_bilinear (:33-84).
+//
+// Lane mapping: lane = channel inside one (batch, query, head).  With the model's D = 32 a wavefront
+// covers two heads of a query; every tap is a contiguous 128-byte row of the value tensor
+// [S, M, D].  The (location, weight) pairs of a head are the same for all of its D lanes: in the
+// D == 32 specialisation each 32-lane half loads them once (lane p < L*P takes sample p) and the
+// bilinear corner offsets / weights are broadcast with wavefront shuffles instead of being re-read
+// and re-derived by every lane.  The generic kernel keeps one lane per output element with the
+// reference's loop structure, for any D, L, P.
+#include "smos_common.h"
+
+namespace smos {
+
+template <typename T>
+__device__ __forceinline__ T bilinear_tap(const T* __restrict__ v, int H, int W, int64_t wstride, T h, T w) {
+  // reference: ms_deform_im2col_cuda.cuh:38-83 (value pointer already offset to head/channel)
+  const int h_low = (int)floor(h), w_low = (int)floor(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const T lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  const int64_t hstride = (int64_t)W * wstride;
+  T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = v[h_low * hstride + w_low * wstride];
+  if (h_low >= 0 && w_high <= W - 1) v2 = v[h_low * hstride + w_high * wstride];
+  if (h_high <= H - 1 && w_low >= 0) v3 = v[h_high * hstride + w_low * wstride];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = v[h_high * hstride + w_high * wstride];
+  const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void msda_fwd_generic(const T* __restrict__ value,
+                                                           const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lsi,
+                                                           const T* __restrict__ loc, const T* __restrict__ attn,
+                                                           T* __restrict__ out, int64_t total, int S, int M, int D,
+                                                           int L, int Lq, int P) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int c = (int)(t % D);
+    t /= D;
+    const int64_t sampling_index = t;  // (b*Lq + q)*M + m
+    const int m = (int)(t % M);
+    t /= M;
+    t /= Lq;
+    const int64_t b = t;
+    int64_t wptr = sampling_index * L * P;
+    int64_t lptr = wptr << 1;
+    const int64_t wstride = (int64_t)M * D;
+    T col = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T* v = value + (b * S + lsi[l]) * wstride + (int64_t)m * D + c;
+      for (int p = 0; p < P; ++p) {
+        const T loc_w = loc[lptr], loc_h = loc[lptr + 1], wt = attn[wptr];
+        const T h_im = loc_h * H - (T)0.5, w_im = loc_w * W - (T)0.5;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) col += bilinear_tap<T>(v, H, W, wstride, h_im, w_im) * wt;
+        wptr += 1;
+        lptr += 2;
+      }
+    }
+    out[idx] = col;
+  }
+}
+
+// D == 32, L*P <= 8, float32: one 32-lane half per (b, q, m); shuffle-broadcast sample metadata.
+// Arithmetic per output element is the same expression tree as the generic kernel.
+__global__ __launch_bounds__(kBlock) void msda_fwd_d32(const float* __restrict__ value,
+                                                       const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                                       const float* __restrict__ attn, float* __restrict__ out,
+                                                       int64_t n_heads_total, int S, int M, int L, int Lq, int P) {
+  const int lane32 = threadIdx.x & 31;
+  const int LP = L * P;
+  const int64_t wstride = (int64_t)M * 32;
+  for (int64_t hq = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5; hq < n_heads_total;
+       hq += ((int64_t)gridDim.x * blockDim.x) >> 5) {
+    const int m = (int)(hq % M);
+    const int64_t b = hq / ((int64_t)M * Lq);
+    // lane p of the half owns sample p: its level, location, weight, corner offsets and weights
+    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+    int co[4] = {-1, -1, -1, -1};
+    float aw = 0.f;
+    if (lane32 < LP) {
+      const int l = lane32 / P;
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const float loc_w = loc[(hq * LP + lane32) * 2], loc_h = loc[(hq * LP + lane32) * 2 + 1];
+      aw = attn[hq * LP + lane32];
+      const float h_im = loc_h * H - 0.5f, w_im = loc_w * W - 0.5f;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        const int base = (int)lsi[l];
+        const bool t = h_low >= 0, bt = h_low + 1 <= H - 1, lf = w_low >= 0, rt = w_low + 1 <= W - 1;
+        co[0] = (t && lf) ? base + h_low * W + w_low : -1;
+        co[1] = (t && rt) ? base + h_low * W + w_low + 1 : -1;
+        co[2] = (bt && lf) ? base + (h_low + 1) * W + w_low : -1;
+        co[3] = (bt && rt) ? base + (h_low + 1) * W + w_low + 1 : -1;
+        cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
+      }
+    }
+    const float* vb = value + (b * S) * wstride + (int64_t)m * 32 + lane32;
+    float col = 0.f;
+    const int half_base = threadIdx.x & 32;  // shuffle sources live in this lane's half of the wave
+    for (int p = 0; p < LP; ++p) {
+      const int src = half_base + p;
+      // same expression tree as the reference: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * weight, absent taps = 0
+      float tap = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int o = __shfl(co[k], src);
+        const float w = __shfl(cw[k], src);
+        const float v = (o >= 0) ? vb[(int64_t)o * wstride] : 0.f;
+        tap += w * v;
+      }
+      col += tap * __shfl(aw, src);
+    }
+    out[hq * 32 + lane32] = col;
+  }
+}
+
+}  // namespace smos
+
+using namespace smos;
+
+extern "C" int smos_msda_fwd(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                             const void* sampling_loc, const void* attn_weight, void* out, int64_t N, int64_t S,
+                             int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P, int32_t dtype,
+                             smos_stream_t stream) {
+  SMOS_REQUIRE(N >= 0 && S >= 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fwd: bad sizes");
+  if (dtype != SMOS_F32 && dtype != SMOS_F64) {
+    set_error("msda_fwd: dtype code %d not implemented (the reference dispatches float/double only)", (int)dtype);
+    return SMOS_ERR_UNSUPPORTED;
+  }
+  const int64_t total = N * Lq * M * D;
+  if (total == 0) return SMOS_OK;
+  SMOS_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+               "msda_fwd: null device pointer");
+  SMOS_REQUIRE(S * M * D < (1LL << 31) && total < (1LL << 40), "msda_fwd: tensor too large for 32-bit tap offsets");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SMOS_F32) {
+    if (D == 32 && L * P <= 8) {
+      const int64_t heads = N * Lq * M;
+      hipLaunchKernelGGL(msda_fwd_d32, dim3(grid_for(heads * 32, kBlock, 256 * 16)), dim3(kBlock), 0, s,
+                         (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc,
+                         (const float*)attn_weight, (float*)out, heads, (int)S, (int)M, (int)L, (int)Lq, (int)P);
+    } else {
+      hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(grid_for(total, kBlock, 256 * 16)), dim3(kBlock), 0, s,
+                         (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc,
+                         (const float*)attn_weight, (float*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
+    }
+  } else {
+    hipLaunchKernelGGL(msda_fwd_generic<double>, dim3(grid_for(total, kBlock, 256 * 16)), dim3(kBlock), 0, s,
+                       (const double*)value, spatial_shapes, level_start_index, (const double*)sampling_loc,
+                       (const double*)attn_weight, (double*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
+  }
+  return check_launch("msda_fwd");
+}

@@ -1,0 +1,180 @@
+"""Tensor-level entry points of the HIP kernels (torch tensors in, C ABI underneath).
+
+torch is used for device memory and streams only: every function launches on
+``torch.cuda.current_stream`` of the tensors' device and returns without synchronising.
+"""
+import torch
+
+from . import _lib, profiling
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+_flag_ws = {}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(name, *tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("%s: expected a tensor in GPU memory, got device=%s (no CPU path here)" % (name, t.device))
+
+
+def _flag(device):
+    ws = _flag_ws.get(device)
+    if ws is None:
+        ws = torch.zeros(4, dtype=torch.int32, device=device)
+        _flag_ws[device] = ws
+    return ws
+
+
+def _dtype_code(name, t):
+    code = _DTYPE_CODE.get(t.dtype)
+    if code is None:
+        raise RuntimeError("%s: unsupported dtype %s" % (name, t.dtype))
+    return code
+
+
+def voxel_maxpool_fwd(feat, ind, out, out_size, scale, voxel_max_idx=None):
+    """feat [BS,C,N(,1)] any strides, ind [BS,N,D(,1)] contiguous, out [BS,C,*out_size] zero-filled."""
+    _require_cuda("voxel_maxpool_fwd", feat, ind, out, voxel_max_idx)
+    if feat.dtype != ind.dtype or feat.dtype != out.dtype:
+        raise RuntimeError("voxel_maxpool_fwd: feat/ind/out dtypes differ (%s, %s, %s)" % (feat.dtype, ind.dtype, out.dtype))
+    if not ind.is_contiguous():
+        raise RuntimeError("voxel_maxpool_fwd: pcds_ind must be contiguous")
+    bs, c, n = feat.shape[0], feat.shape[1], feat.shape[2]
+    d = ind.shape[2]
+    if len(out_size) != d or len(scale) != d or ind.shape[0] != bs or ind.shape[1] != n:
+        raise RuntimeError("voxel_maxpool_fwd: shape mismatch feat %s ind %s out_size %s" % (tuple(feat.shape), tuple(ind.shape), tuple(out_size)))
+    if tuple(out.shape) != (bs, c) + tuple(int(s) for s in out_size):
+        raise RuntimeError("voxel_maxpool_fwd: out has shape %s" % (tuple(out.shape),))
+    if voxel_max_idx is not None and (voxel_max_idx.dtype != torch.int64 or not voxel_max_idx.is_contiguous()):
+        raise RuntimeError("voxel_maxpool_fwd: voxel_max_idx must be contiguous int64")
+    lib = _lib.load()
+    label = "voxel_maxpool_fwd[%dx%dx%d->%s]" % (bs, c, n, "x".join(str(int(s)) for s in out_size))
+    with torch.cuda.device(feat.device), profiling.span(label):
+        rc = lib.smos_voxel_maxpool_fwd(
+            feat.data_ptr(), _lib.i64_array(feat.stride()[:3]), ind.data_ptr(), out.data_ptr(),
+            _lib.i64_array(out.stride()), voxel_max_idx.data_ptr() if voxel_max_idx is not None else None,
+            bs, c, n, d, _lib.i64_array(out_size), _lib.f32_array(scale), _dtype_code("voxel_maxpool_fwd", feat),
+            _flag(feat.device).data_ptr(), _stream(feat))
+    _lib.check(rc, "smos_voxel_maxpool_fwd")
+    return out
+
+
+def voxel_maxpool_bwd(feat, ind, out, grad_out, grad_feat, out_size, scale):
+    _require_cuda("voxel_maxpool_bwd", feat, ind, out, grad_out, grad_feat)
+    if grad_out.stride() != out.stride():
+        grad_out = grad_out.contiguous()
+        if grad_out.stride() != out.stride():
+            raise RuntimeError("voxel_maxpool_bwd: grad_out strides must match out")
+    if grad_feat.stride() != feat.stride():
+        raise RuntimeError("voxel_maxpool_bwd: grad_feat strides must match feat")
+    bs, c, n = feat.shape[0], feat.shape[1], feat.shape[2]
+    lib = _lib.load()
+    with torch.cuda.device(feat.device):
+        rc = lib.smos_voxel_maxpool_bwd(
+            feat.data_ptr(), _lib.i64_array(feat.stride()[:3]), ind.data_ptr(), out.data_ptr(), grad_out.data_ptr(),
+            _lib.i64_array(out.stride()), grad_feat.data_ptr(), bs, c, n, ind.shape[2], _lib.i64_array(out_size),
+            _lib.f32_array(scale), _dtype_code("voxel_maxpool_bwd", feat), _stream(feat))
+    _lib.check(rc, "smos_voxel_maxpool_bwd")
+    return grad_feat
+
+
+def bilinear_gather(grid, coord, scale, out=None, point_major=False):
+    """grid [B,C,H,W] (any strides), coord [B,N,K(,1)] -> out [B,C,N] (a view of a [B,N,C] buffer when
+    point_major)."""
+    _require_cuda("bilinear_gather", grid, coord, out)
+    if grid.dtype != torch.float32 or coord.dtype != torch.float32:
+        raise RuntimeError("bilinear_gather: float32 only (got %s, %s)" % (grid.dtype, coord.dtype))
+    if coord.dim() == 4:
+        coord = coord[..., 0]
+    if not coord.is_contiguous():
+        coord = coord.contiguous()
+    b, c, h, w = grid.shape
+    n, k = coord.shape[1], coord.shape[2]
+    if out is None:
+        if point_major:
+            out = torch.empty((b, n, c), dtype=torch.float32, device=grid.device).permute(0, 2, 1)
+        else:
+            out = torch.empty((b, c, n), dtype=torch.float32, device=grid.device)
+    lib = _lib.load()
+    with torch.cuda.device(grid.device), profiling.span("bilinear_gather[%dx%dx%dx%d->%d]" % (b, c, h, w, n)):
+        rc = lib.smos_bilinear_gather_fwd(grid.data_ptr(), _lib.i64_array(grid.stride()), coord.data_ptr(), k,
+                                          out.data_ptr(), _lib.i64_array(out.stride()[:3]), b, c, h, w, n,
+                                          _lib.f32_array(scale), _stream(grid))
+    _lib.check(rc, "smos_bilinear_gather_fwd")
+    return out
+
+
+def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    """value [N,S,M,D], shapes [L,2] int64 (device), level_start [L] int64 (device), loc [N,Lq,M,L,P,2],
+    attn [N,Lq,M,L,P] -> [N,Lq,M*D]."""
+    _require_cuda("ms_deform_attn_forward", value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    n, s, m, d = value.shape
+    lq, l, p = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+    lib = _lib.load()
+    with torch.cuda.device(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+        rc = lib.smos_msda_fwd(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                               sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), n, s, m, d, l, lq, p,
+                               _dtype_code("ms_deform_attn_forward", value), _stream(value))
+    _lib.check(rc, "smos_msda_fwd")
+    return out
+
+
+def tta_argmax(pred, want_prob=False):
+    """pred [B,K,N(,1)] float32 -> labels [N] uint8 (and prob [N,K])."""
+    _require_cuda("tta_argmax", pred)
+    if pred.dim() == 4:
+        pred = pred[..., 0]
+    pred = pred.contiguous().float()
+    b, k, n = pred.shape
+    labels = torch.empty(n, dtype=torch.uint8, device=pred.device)
+    prob = torch.empty((n, k), dtype=torch.float32, device=pred.device) if want_prob else None
+    lib = _lib.load()
+    with torch.cuda.device(pred.device):
+        rc = lib.smos_tta_argmax(pred.data_ptr(), b, k, n, labels.data_ptr(), prob.data_ptr() if want_prob else None,
+                                 _stream(pred))
+    _lib.check(rc, "smos_tta_argmax")
+    return (labels, prob) if want_prob else labels
+
+
+def vote_clear(table):
+    _require_cuda("vote_clear", table)
+    lib = _lib.load()
+    with torch.cuda.device(table.device):
+        rc = lib.smos_vote_clear(table.data_ptr(), _stream(table))
+    _lib.check(rc, "smos_vote_clear")
+
+
+def vote_accumulate(points, labels, table, pose_diff=None, recip_quantize=False):
+    """points [n, >=3] float32 rows, labels [n] uint8, pose_diff 4x4 (numpy float64) or None."""
+    _require_cuda("vote_accumulate", points, labels, table)
+    if points.dtype != torch.float32 or labels.dtype != torch.uint8 or points.stride(1) != 1:
+        raise RuntimeError("vote_accumulate: points must be float32 rows and labels uint8")
+    pose = None
+    if pose_diff is not None:
+        pose = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        rc = lib.smos_vote_accumulate(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(), pose,
+                                      1 if recip_quantize else 0, table.data_ptr(), _stream(points))
+    _lib.check(rc, "smos_vote_accumulate")
+
+
+def vote_resolve(points, labels, table, lut=None, recip_quantize=False):
+    _require_cuda("vote_resolve", points, labels, table, lut)
+    out = torch.empty(points.shape[0], dtype=torch.int32, device=points.device)
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        rc = lib.smos_vote_resolve(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(),
+                                   1 if recip_quantize else 0, table.data_ptr(),
+                                   lut.data_ptr() if lut is not None else None, out.data_ptr(), _stream(points))
+    _lib.check(rc, "smos_vote_resolve")
+    return out

@@ -1,0 +1,54 @@
+"""Per-kernel timing with HIP events on the stream the kernels are launched on.
+
+``ops`` brackets every C-ABI launch with ``record(label)`` when a timer is active.  Events are
+``torch.cuda.Event`` objects recorded on ``torch.cuda.current_stream`` -- the very stream whose handle is
+passed to the C ABI -- so they time exactly the kernels of that launch.
+"""
+import contextlib
+
+import torch
+
+_active = None
+
+
+class KernelTimer:
+    def __init__(self, only=None):
+        self.only = only            # label filter (None = every launch)
+        self.events = {}            # label -> list of (start, stop)
+
+    @contextlib.contextmanager
+    def span(self, label):
+        if self.only is not None and label != self.only:
+            yield
+            return
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.events.setdefault(label, []).append((a, b))
+
+    def summary(self):
+        """label -> (calls, total_ms, mean_ms); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for label, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[label] = (len(ms), float(sum(ms)), float(sum(ms) / len(ms)))
+        return out
+
+
+@contextlib.contextmanager
+def kernel_timer(only=None):
+    global _active
+    prev, _active = _active, KernelTimer(only)
+    try:
+        yield _active
+    finally:
+        _active = prev
+
+
+def span(label):
+    if _active is None:
+        return contextlib.nullcontext()
+    return _active.span(label)

@@ -1,0 +1,89 @@
+"""``models.StreamMOS.AttNet`` -- the streaming moving-object-segmentation network
+(mirror of models/StreamMOS.py:22-202).
+
+Same constructor argument (the ``ModelParam`` config class), the same 474-key ``state_dict`` and the
+same ``infer(batch, i, query_embed_store)`` / ``stage_forward(...)`` contracts, so the reference's
+``val_StreamMOS.py`` flow -- ``load_state_dict`` -> ``SyncBatchNorm.convert_sync_batchnorm`` -> DDP ->
+optimizer -> ``.infer`` -- runs on this class unchanged.  The point<->grid scatters, the bilinear
+gathers and the deformable-attention sampler underneath are the HIP kernels of libsmos_hip.so.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from ..networks import backbone, multi_view_encoder
+from ..networks.backbone import get_module
+from .. import deep_point
+
+
+def VoxelMaxPool(pcds_feat, pcds_ind, output_size, scale_rate):
+    out = deep_point.VoxelMaxPool(pcds_feat=pcds_feat.float(), pcds_ind=pcds_ind, output_size=output_size,
+                                  scale_rate=scale_rate)
+    return out.to(pcds_feat.dtype)
+
+
+class AttNet(nn.Module):
+    def __init__(self, pModel):
+        super().__init__()
+        self.pModel = pModel
+        vox = pModel.Voxel
+        self.bev_shape = list(vox.bev_shape)
+        self.rv_shape = list(vox.rv_shape)
+        self.bev_wl_shape = self.bev_shape[:2]
+        self.dx = (vox.range_x[1] - vox.range_x[0]) / vox.bev_shape[0]
+        self.dy = (vox.range_y[1] - vox.range_y[0]) / vox.bev_shape[1]
+        self.dz = (vox.range_z[1] - vox.range_z[0]) / vox.bev_shape[2]
+        self.point_feat_out_channels = pModel.point_feat_out_channels
+        self.build_network()
+        self._engine = None
+
+    def build_network(self):
+        p = self.pModel
+        context = copy.deepcopy(p.BEVParam.context_layers)
+        point_channels = context[0]
+        context[0] = p.seq_num * context[0]          # T stacked scans share the BEV input (StreamMOS.py:74)
+        self.point_pre = backbone.PointNetStacker(7, point_channels, pre_bn=True, stack_num=2)
+        self.bev_net = multi_view_encoder.CENet_Transformer(p.BEVParam.base_block, context,
+                                                            copy.deepcopy(p.BEVParam.layers), p.class_num, use_att=True)
+        self.bev_grid2point = get_module(p.BEVParam.bev_grid2point, in_dim=self.bev_net.out_channels)
+        fusion = {"CatFusion": backbone.CatFusion}[p.fusion_mode]
+        self.point_post = fusion(in_channel_list=(point_channels, self.bev_net.out_channels, 64),
+                                 out_channel=self.point_feat_out_channels)
+        self.pred_layer = backbone.PredBranch(self.point_feat_out_channels, p.class_num)
+
+    # ------------------------------------------------------------------------------------
+    def stage_forward(self, point_feat, pcds_coord, pcds_sphere_coord, query_embed_store=None, use_query_store=False,
+                      return_query=False):
+        """point_feat (BS,T,C,N,1), pcds_coord (BS,T,N,3,1), pcds_sphere_coord (BS,T,N,2,1)
+        -> pred_cls (BS,class_num,N,1), three BEV aux maps, new memory (BS,128,64,64)   [StreamMOS.py:86-113]"""
+        bs, t, c, n, _ = point_feat.shape
+        cur_xy = pcds_coord[:, 0, :, :2].contiguous()
+        cur_sphere = pcds_sphere_coord[:, 0].contiguous()
+
+        pts = self.point_pre(point_feat.view(bs * t, c, n, 1))
+        bev = VoxelMaxPool(pcds_feat=pts, pcds_ind=pcds_coord.view(bs * t, n, 3, 1)[:, :, :2].contiguous(),
+                           output_size=self.bev_wl_shape, scale_rate=(1.0, 1.0))
+        bev = bev.view(bs, -1, self.bev_wl_shape[0], self.bev_wl_shape[1])
+        bev_feat, point_feat_1, aux0, aux1, aux2, memory = self.bev_net(
+            bev, cur_xy, cur_sphere, query_embed_store, use_query_store, True)
+        point_bev = self.bev_grid2point(bev_feat, cur_xy)
+
+        pts_cur = pts.view(bs, t, -1, n, 1)[:, 0].contiguous()
+        fused = self.point_post(pts_cur, point_bev, point_feat_1)
+        pred_cls = self.pred_layer(fused).float()
+        return pred_cls, aux0, aux1, aux2, memory
+
+    def infer(self, batch, i, query_embed_store=None):
+        """One streamed scan.  ``batch`` tensors carry the DataLoader's leading dim of 1, which is squeezed
+        here (StreamMOS.py:181-202); frame 0 starts from the learned memory embedding."""
+        args = (batch["pcds_xyzi"].squeeze(0), batch["pcds_coord"].squeeze(0), batch["pcds_sphere_coord"].squeeze(0))
+        if i == 0:
+            return self.stage_forward(*args, return_query=True)
+        return self.stage_forward(*args, query_embed_store=query_embed_store, use_query_store=True, return_query=True)
+
+    def forward(self, batch):
+        raise NotImplementedError(
+            "AttNet.forward (three chained training steps with OHEM-CE + Lovasz losses, models/StreamMOS.py:155-179) "
+            "belongs to the training row f2 of SURVEY.md section 8, which this build has not reached; inference "
+            "goes through .infer()/.stage_forward()")

@@ -1,0 +1,138 @@
+"""Streaming runner: one LiDAR sequence = one stream (recurrent memory + voting window).
+
+Does on the device what the reference spreads over ``val_StreamMOS.py:88-126`` (infer, softmax / TTA
+mean / argmax, un-pad, scatter through the range mask) and ``voxel_voting.py:176-249`` (8-frame
+voxel voting) -- the latter without its per-frame disk round trip: the last eight scans and their
+predictions stay resident in HBM and are re-voxelised in the current frame's coordinates by the
+voting kernels.
+
+Sequences are independent streams: multi-GPU inference assigns whole sequences to
+ranks (``shard_sequences``) and needs no collective.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import ops
+
+VOTE_WINDOW = 8                      # frames_num_max, voxel_voting.py:140
+LEARNING_MAP_INV = {0: 0, 1: 9, 2: 251}   # config/StreamMOS.py:58
+
+
+def shard_sequences(lengths, world_size):
+    """Longest-processing-time-first assignment of whole sequences to ranks.
+    lengths: {sequence_id: n_scans}.  Returns a list (one entry per rank) of sequence-id lists."""
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for seq, n in sorted(lengths.items(), key=lambda kv: (-kv[1], str(kv[0]))):
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(seq)
+        loads[r] += n
+    return shards
+
+
+def vote_history_ids(frame_id, window=VOTE_WINDOW):
+    """voxel_voting.py:177-212: frames >= window use the previous `window` frames; earlier frames use
+    frames 0..window-1 except themselves (i.e. also *future* frames)."""
+    if frame_id >= window:
+        return list(range(frame_id - 1, frame_id - window - 1, -1))
+    return [k for k in range(window) if k != frame_id]
+
+
+class VoxelVoter:
+    """HBM-resident voting window.  ``push`` takes a frame (raw points in its own sensor frame, per-point
+    predictions in {0,1,2}, 4x4 pose) and returns the frames whose refined labels became available:
+    a list of (frame_id, int32 labels tensor)."""
+
+    def __init__(self, device, window=VOTE_WINDOW, lut=LEARNING_MAP_INV, recip_quantize=False):
+        self.device = torch.device(device)
+        self.window = window
+        self.recip = recip_quantize
+        self.table = torch.zeros(512 * 512 * 30, dtype=torch.int64, device=self.device)
+        self.lut = None
+        if lut is not None:
+            t = torch.zeros(256, dtype=torch.int32)
+            for k, v in lut.items():
+                t[k] = v
+            self.lut = t.to(self.device)
+        self.frames = collections.OrderedDict()     # frame_id -> (points, preds, pose)
+        self.next_id = 0
+
+    def reset(self):
+        self.frames.clear()
+        self.next_id = 0
+
+    def _vote(self, fid):
+        pts, pred, pose = self.frames[fid]
+        inv_cur = np.linalg.inv(pose)
+        ops.vote_clear(self.table)
+        for h in vote_history_ids(fid, self.window):
+            if h not in self.frames:
+                continue
+            hp, hl, hpose = self.frames[h]
+            ops.vote_accumulate(hp, hl, self.table, pose_diff=inv_cur.dot(hpose), recip_quantize=self.recip)
+        ops.vote_accumulate(pts, pred, self.table, recip_quantize=self.recip)
+        return ops.vote_resolve(pts, pred, self.table, lut=self.lut, recip_quantize=self.recip)
+
+    def push(self, points, preds, pose):
+        fid = self.next_id
+        self.next_id += 1
+        self.frames[fid] = (points, preds, np.asarray(pose, dtype=np.float64))
+        ready = []
+        if fid == self.window - 1:
+            ready = [(k, self._vote(k)) for k in range(self.window)]
+        elif fid >= self.window:
+            ready = [(fid, self._vote(fid))]
+            self.frames.pop(fid - self.window, None)
+        return ready
+
+    def flush(self):
+        """End of a sequence shorter than the window: vote with whatever frames exist."""
+        if self.next_id < self.window:
+            return [(k, self._vote(k)) for k in range(self.next_id)]
+        return []
+
+
+class StreamRunner:
+    """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
+
+    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False):
+        self.device = torch.device(device)
+        self.model = model.to(self.device).eval()
+        self.voter = VoxelVoter(self.device, recip_quantize=recip_quantize) if vote else None
+        self.reset()
+
+    def reset(self):
+        self.memory = None
+        self.frame = 0
+        if self.voter is not None:
+            self.voter.reset()
+
+    def upload(self, sample, raw_scan=None):
+        """Host sample (streammos_amd.preprocess.build_sample) -> device-resident inputs."""
+        dev = {k: torch.from_numpy(np.ascontiguousarray(sample[k])).to(self.device)
+               for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+        dev["valid_index"] = torch.from_numpy(np.nonzero(sample["valid_mask"])[0]).to(self.device)
+        dev["n_raw"] = int(sample["valid_mask"].shape[0])
+        dev["n_valid"] = int(sample["valid_mask"].sum())
+        if raw_scan is not None:
+            dev["raw_scan"] = torch.from_numpy(np.ascontiguousarray(raw_scan)).to(self.device)
+        return dev
+
+    @torch.no_grad()
+    def step(self, dev, pose=None):
+        """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
+        voted = [(frame_id, int32 LUT labels)])."""
+        batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+        pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
+        labels = ops.tta_argmax(pred_cls)
+        out = {"pred_cls": pred_cls, "labels": labels, "voted": []}
+        if "valid_index" in dev:
+            raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
+            raw.index_copy_(0, dev["valid_index"], labels[:dev["n_valid"]])      # val_StreamMOS.py:112-118
+            out["raw_labels"] = raw
+            if self.voter is not None and "raw_scan" in dev:
+                out["voted"] = self.voter.push(dev["raw_scan"], raw, pose if pose is not None else np.eye(4))
+        self.frame += 1
+        return out

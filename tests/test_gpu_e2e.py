@@ -1,0 +1,95 @@
+"""End-to-end parity of AttNet.infer on the GPU (HIP kernels + PyTorch-ROCm convs) against the golden
+vectors of the real reference and against the CPU oracle, plus the streaming runner with voting."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_torch, ops_np
+from streammos_amd import preprocess, streaming, synth
+from streammos_amd.refapi.config import StreamMOS as cfg
+from streammos_amd.refapi.models import StreamMOS
+from tests import cases
+from tests.util import check_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = StreamMOS.AttNet(cfg.get_config()[2])
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict()), strict=True)
+    return m.to(DEV).eval()
+
+
+def test_infer_matches_reference_golden(golden, model):
+    g = golden("e2e")
+    memory = None
+    with torch.no_grad():
+        for i, batch in enumerate(cases.e2e_frames()):
+            check_inputs(g, "e2e_f%d_in_sha" % i, batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"])
+            tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+            pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+            ref = g["e2e_f%d_pred" % i]
+            got = pred.cpu().numpy()
+            # fp32 everywhere; MIOpen vs MKL-DNN summation order over ~40 layers: 1e-3 of the logit range,
+            # which keeps >= 99.5 % of the argmax labels (north_star budget: +-0.1 moving IoU)
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+            assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.995
+            np.testing.assert_allclose(memory[:, ::8, ::4, ::4].cpu().numpy(), g["e2e_f%d_mem_sub" % i], rtol=0, atol=2e-3)
+            stats = g["e2e_f%d_mem_stats" % i]
+            assert abs(memory.double().abs().sum().item() - stats[1]) <= 1e-4 * stats[1]
+            aux = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].cpu().numpy()
+            ref_aux = g["e2e_f%d_aux_sub" % i]
+            assert np.abs(aux - ref_aux).max() <= 1e-3 * np.abs(ref_aux).max()
+
+
+def test_stream_runner_with_voting_matches_oracle(model):
+    """6 frames of a small synthetic sequence through StreamRunner (window shortened to 4 so that both the
+    look-ahead start-up phase and the steady state run), predictions and voted labels vs the CPU oracle."""
+    spec = preprocess.VoxelSpec()
+    n_frames = 6
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(n_frames + 2)]
+    poses = [synth.synthetic_pose(k) for k in range(n_frames + 2)]
+    runner = streaming.StreamRunner(model, DEV, vote=True)
+    runner.voter.window = 4
+    oracle = net_torch.OracleNet({k: v.cpu() for k, v in model.state_dict().items()})
+    memory = None
+    raw_preds, voted = [], {}
+    for i in range(n_frames):
+        idx = preprocess.window_indices(i, n_frames + 2, 3)
+        sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+        out = runner.step(runner.upload(sample, scans[i]), poses[i])
+        want, _, _, _, memory = oracle.stage_forward(*(torch.from_numpy(sample[k]) for k in
+                                                       ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), memory)
+        want_lab, _ = net_torch.tta_labels(want)
+        agree = (out["labels"].cpu().long() == want_lab).float().mean().item()
+        assert agree >= 0.995, (i, agree)
+        raw_preds.append(out["raw_labels"].cpu().numpy())
+        for fid, lab in out["voted"]:
+            voted[fid] = lab.cpu().numpy()
+    assert sorted(voted) == list(range(n_frames))
+    # voting is integer work: given the SAME per-point predictions it must be bit-exact with the oracle
+    lut = np.zeros(256, dtype=np.int32)
+    lut[1], lut[2] = 9, 251
+    for fid in range(n_frames):
+        hist_ids = streaming.vote_history_ids(fid, 4)
+        inv_cur = np.linalg.inv(poses[fid])
+        hp = np.concatenate([preprocess.pose_align(scans[h], inv_cur.dot(poses[h])) for h in hist_ids], 0)
+        hl = np.concatenate([raw_preds[h] for h in hist_ids], 0)
+        want = ops_np.vote_frame(scans[fid], raw_preds[fid], hp, hl)
+        assert np.array_equal(voted[fid], lut[want]), fid
+
+
+def test_model_survives_reference_val_wrapping(model):
+    """val_StreamMOS.py:188-195: SyncBatchNorm conversion + optimizer construction around the net."""
+    import copy
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(model)).to(DEV).eval()
+    torch.optim.SGD(m.parameters(), lr=0.02, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    assert list(m.state_dict().keys()) == list(model.state_dict().keys())
+    batch = next(iter(cases.e2e_frames(1)))
+    tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        a = m.infer(tb, 0)[0]
+        b = model.infer(tb, 0)[0]
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()

@@ -1,0 +1,229 @@
+"""Parity of the HIP kernels (through the C ABI) against the golden vectors and the CPU oracle.
+
+Bars: bit-exact for the scatter (max is order independent) and for every voting index / label;
+for the floating-point gathers and the deformable sampler the tolerance is written at the assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np
+from streammos_amd import ops
+from streammos_amd.refapi import deep_point
+from streammos_amd.refapi.deformattn.functions import MSDeformAttnFunction
+from tests import cases
+from tests.util import check_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------
+# VoxelMaxPool
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.voxel_maxpool_cases()))
+def test_voxel_maxpool_golden(golden, name):
+    g = golden("ops_voxel_maxpool")
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()[name]
+    check_inputs(g, "vmp_%s_in_sha" % name, feat, ind)
+    f = _t(feat).unsqueeze(-1).requires_grad_(True)
+    y = deep_point.VoxelMaxPool(f, _t(ind).unsqueeze(-1), out_size, scale)
+    assert np.array_equal(y.detach().cpu().numpy(), g["vmp_%s_out" % name])
+    y.backward(_t(cases.grad_like(y.shape, name)))
+    assert np.array_equal(f.grad[..., 0].cpu().numpy(), g["vmp_%s_grad" % name])
+
+
+@pytest.mark.parametrize("name", sorted(cases.voxel_maxpool_cases()))
+def test_voxel_maxpool_channels_last_rows_kernel(golden, name):
+    """point-major features + channels-last grid take the "rows" lane mapping; same numbers."""
+    g = golden("ops_voxel_maxpool")
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()[name]
+    bs, c, n = feat.shape
+    reps = max(1, 8 // c + 1)                          # the rows kernel needs C >= 8: tile the channels
+    feat_w = np.concatenate([feat] * reps, axis=1)
+    f = _t(feat_w.transpose(0, 2, 1)).permute(0, 2, 1)                 # [BS,C,N] view of a [BS,N,C] buffer
+    out = torch.zeros((bs,) + tuple(out_size) + (c * reps,), device=DEV)
+    out_v = out.movedim(-1, 1)                                           # [BS,C,*size] view, channel stride 1
+    idx = torch.full((bs, n), -1, dtype=torch.int64, device=DEV)
+    ops.voxel_maxpool_fwd(f, _t(ind), out_v, out_size, scale, voxel_max_idx=idx)
+    want = np.concatenate([g["vmp_%s_out" % name]] * reps, axis=1)
+    assert np.array_equal(out_v.cpu().numpy(), want)
+    assert np.array_equal((idx >= 0).cpu().numpy(), ops_np.voxel_cell_index(ind, out_size, scale) >= 0)
+
+
+def test_voxel_maxpool_voxel_max_idx_matches_reference_definition():
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()["basic"]
+    f, i = _t(feat), _t(ind)
+    out = torch.zeros((feat.shape[0], feat.shape[1]) + tuple(out_size), device=DEV)
+    idx = torch.full(ind.shape[:2], -1, dtype=torch.int64, device=DEV)
+    ops.voxel_maxpool_fwd(f, i, out, out_size, scale, voxel_max_idx=idx)
+    _, want = ops_np.voxel_maxpool_fwd(feat, ind, out_size, scale)
+    assert np.array_equal(idx.cpu().numpy(), want)
+
+
+def test_voxel_maxpool_full_size_properties():
+    """BASELINE shape of the input scatter (12 x 64 x 160000 -> 512 x 512): compared bit-exactly with an
+    independent formulation (torch scatter_reduce amax on the GPU), plus permutation invariance and
+    idempotence (pooling the pooled grid's own occupied cells changes nothing)."""
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    bs, c, n = 12, 64, 160000
+    feat = torch.relu(torch.randn((bs, c, n), generator=gen)).to(DEV)
+    ind = (torch.rand((bs, n, 2), generator=gen) * 560.0 - 24.0)
+    ind[:, -30000:] = -4864.0                                   # the reference's padding rows
+    ind = ind.to(DEV)
+    out = torch.zeros((bs, c, 512, 512), device=DEV)
+    ops.voxel_maxpool_fwd(feat, ind, out, (512, 512), (1.0, 1.0))
+    cy, cx = ind[..., 0].double().trunc(), ind[..., 1].double().trunc()
+    ok = (ind[..., 0] > -1) & (cy < 512) & (ind[..., 1] > -1) & (cx < 512)
+    flat = torch.where(ok, cy * 512 + cx, torch.full_like(cy, 512 * 512)).long()
+    want = torch.zeros((bs, c, 512 * 512 + 1), device=DEV)
+    want.scatter_reduce_(2, flat[:, None, :].expand(bs, c, n), feat, "amax", include_self=False)
+    assert torch.equal(out.view(bs, c, -1), want[:, :, :-1])
+    perm = torch.randperm(n, generator=gen).to(DEV)
+    out2 = torch.zeros_like(out)
+    ops.voxel_maxpool_fwd(feat[:, :, perm].contiguous(), ind[:, perm].contiguous(), out2, (512, 512), (1.0, 1.0))
+    assert torch.equal(out, out2)
+    ops.voxel_maxpool_fwd(feat, ind, out2, (512, 512), (1.0, 1.0))      # idempotent on a filled grid
+    assert torch.equal(out, out2)
+
+
+def test_voxel_maxpool_errors_are_loud():
+    f = torch.zeros((1, 2, 4, 1), device=DEV, dtype=torch.float16)
+    i = torch.zeros((1, 4, 2, 1), device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        deep_point.VoxelMaxPool(f, i, (4, 4), (1.0, 1.0))
+    with pytest.raises(RuntimeError):
+        ops.voxel_maxpool_fwd(torch.zeros(1, 2, 4), torch.zeros(1, 4, 2), torch.zeros(1, 2, 4, 4), (4, 4), (1.0, 1.0))
+
+
+# ------------------------------------------------------------------------------------------
+# BilinearSample
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.bilinear_cases()))
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_bilinear_gather(golden, name, layout):
+    g = golden("ops_bilinear")
+    grid, coord, scale = cases.bilinear_cases()[name]
+    check_inputs(g, "bil_%s_in_sha" % name, grid, coord)
+    reps = 1 if layout == "nchw" else 4
+    grid_w = np.concatenate([grid] * reps, axis=1)
+    gt = _t(grid_w)
+    if layout == "nhwc":
+        gt = gt.contiguous(memory_format=torch.channels_last)
+    out = ops.bilinear_gather(gt, _t(coord), scale, point_major=(layout == "nhwc"))
+    want = np.concatenate([g["bil_%s_out" % name]] * reps, axis=1)
+    # float32 four-tap blend of O(1) values; FMA contraction vs ATen's separate mul/add: <= 1e-6 abs
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), np.concatenate([ops_np.bilinear_sample(grid, coord, scale)] * reps, 1),
+                               rtol=0, atol=2e-6)
+
+
+def test_bilinear_gather_model_shape_against_grid_sample():
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    grid = torch.randn((4, 32, 256, 256), generator=gen).to(DEV)
+    coord = (torch.rand((4, 160000, 2), generator=gen) * 560 - 24).to(DEV)
+    coord[:, -20000:] = -4864.0
+    out = ops.bilinear_gather(grid, coord, (0.5, 0.5))
+    gx = (2 * coord[:, :, 1] * 0.5 / 255) - 1
+    gy = (2 * coord[:, :, 0] * 0.5 / 255) - 1
+    want = torch.nn.functional.grid_sample(grid, torch.stack((gx, gy), -1)[:, :, None], mode="bilinear",
+                                           padding_mode="zeros", align_corners=True)[..., 0]
+    assert (out - want).abs().max().item() <= 5e-6
+
+
+# ------------------------------------------------------------------------------------------
+# deformable attention sampler
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.msda_cases()))
+def test_msda_forward(golden, name):
+    g = golden("ops_msda")
+    value, shapes, lsi, loc, attn = cases.msda_cases()[name]
+    check_inputs(g, "msda_%s_in_sha" % name, value, shapes, lsi, loc, attn)
+    out32 = MSDeformAttnFunction.apply(_t(value), _t(shapes), _t(lsi), _t(loc), _t(attn), 256)
+    # the reference's own float check allows rtol 1e-2 / atol 1e-3 (deformattn/test.py:58); we hold 1e-5 / 1e-7
+    np.testing.assert_allclose(out32.cpu().numpy(), g["msda_%s_out32" % name], rtol=1e-5, atol=1e-7)
+    out64 = MSDeformAttnFunction.apply(_t(value).double(), _t(shapes), _t(lsi), _t(loc).double(), _t(attn).double(), 256)
+    # deformattn/test.py:41: torch.allclose defaults in double
+    np.testing.assert_allclose(out64.cpu().numpy(), g["msda_%s_out64" % name], rtol=1e-5, atol=1e-8)
+
+
+def test_msda_model_shape_fast_path_equals_generic_path():
+    """D=32, one 64x64 level, 4 heads x 4 points (the model's shape): the shuffle kernel must agree with
+    the generic kernel (forced by viewing the same data as float64) to float32 rounding."""
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    n, s, m, d, lq, p = 4, 4096, 4, 32, 4096, 4
+    value = torch.randn((n, s, m, d), generator=gen).to(DEV)
+    loc = (torch.rand((n, lq, m, 1, p, 2), generator=gen) * 1.2 - 0.1).to(DEV)
+    attn = torch.softmax(torch.randn((n, lq, m, p), generator=gen), -1).view(n, lq, m, 1, p).to(DEV)
+    shapes = torch.tensor([[64, 64]], device=DEV)
+    lsi = torch.zeros(1, dtype=torch.long, device=DEV)
+    fast = ops.msda_fwd(value, shapes, lsi, loc, attn)
+    slow = ops.msda_fwd(value.double(), shapes, lsi, loc.double(), attn.double())
+    assert (fast.double() - slow).abs().max().item() <= 2e-5
+    want = ops_np.msda_forward(value[:1, :, :, :].cpu().numpy(), [[64, 64]], [0], loc[:1, :256].cpu().numpy(),
+                               attn[:1, :256].cpu().numpy())
+    np.testing.assert_allclose(fast[:1, :256].cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_msda_rejects_cpu_and_noncontiguous():
+    value, shapes, lsi, loc, attn = cases.msda_cases()["model"]
+    with pytest.raises(RuntimeError):
+        MSDeformAttnFunction.apply(torch.from_numpy(value), torch.from_numpy(shapes), torch.from_numpy(lsi),
+                                   torch.from_numpy(loc), torch.from_numpy(attn), 256)
+    with pytest.raises(RuntimeError):
+        ops.msda_fwd(_t(value).transpose(2, 3), _t(shapes), _t(lsi), _t(loc), _t(attn))
+
+
+# ------------------------------------------------------------------------------------------
+# voting + TTA reduce
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.voting_cases()))
+def test_vote_kernels_bit_exact(golden, name):
+    g = golden("ops_voting")
+    cur, cur_pred, hist, hist_pred = cases.voting_cases()[name]
+    check_inputs(g, "vote_%s_in_sha" % name, cur, cur_pred, hist, hist_pred)
+    table = torch.empty(512 * 512 * 30, dtype=torch.int64, device=DEV)
+    ops.vote_clear(table)
+    ops.vote_accumulate(_t(hist), _t(hist_pred.astype(np.uint8)), table)
+    ops.vote_accumulate(_t(cur), _t(cur_pred.astype(np.uint8)), table)
+    refined = ops.vote_resolve(_t(cur), _t(cur_pred.astype(np.uint8)), table)
+    assert np.array_equal(refined.cpu().numpy(), g["vote_%s_refined" % name])
+    lut = torch.zeros(256, dtype=torch.int32, device=DEV)
+    lut[1], lut[2] = 9, 251
+    mapped = ops.vote_resolve(_t(cur), _t(cur_pred.astype(np.uint8)), table, lut=lut)
+    assert np.array_equal(mapped.cpu().numpy(), g["vote_%s_lut" % name])
+    # the packed table against the reference's dense argmax, at every voxel that received a vote
+    t = table.cpu().numpy().astype(np.uint64)
+    c = np.stack(((t >> np.uint64(0)) & np.uint64(0x1FFFFF), (t >> np.uint64(21)) & np.uint64(0x1FFFFF),
+                  (t >> np.uint64(42)) & np.uint64(0x1FFFFF)), -1)
+    lab = c.argmax(-1)
+    nz = np.nonzero(lab)[0]
+    assert np.array_equal(nz, g["vote_%s_voxel_nz_idx" % name])
+    assert np.array_equal(lab[nz], g["vote_%s_voxel_nz_val" % name])
+
+
+def test_vote_pose_transform_matches_float64_host_path():
+    from streammos_amd import preprocess, synth
+    scan = synth.synthetic_scan(5, 32, 400)
+    pose = np.linalg.inv(synth.synthetic_pose(9)).dot(synth.synthetic_pose(5))
+    pred = np.random.Generator(np.random.PCG64(1)).integers(0, 3, scan.shape[0]).astype(np.uint8)
+    moved = preprocess.pose_align(scan, pose)
+    t_dev = torch.zeros(512 * 512 * 30, dtype=torch.int64, device=DEV)
+    t_host = torch.zeros_like(t_dev)
+    ops.vote_accumulate(_t(scan), _t(pred), t_dev, pose_diff=pose)
+    ops.vote_accumulate(_t(moved), _t(pred), t_host)
+    assert torch.equal(t_dev, t_host)
+
+
+def test_tta_argmax_matches_torch():
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    pred = (torch.randn((4, 3, 50000, 1), generator=gen) * 3).to(DEV)
+    labels, prob = ops.tta_argmax(pred, want_prob=True)
+    want = torch.softmax(pred, 1).mean(0).permute(2, 1, 0).squeeze(0)
+    assert (prob - want).abs().max().item() <= 1e-6
+    agree = (labels.long() == want.argmax(1)).float().mean().item()
+    assert agree == 1.0 or ((prob.sort(1)[0][:, -1] - prob.sort(1)[0][:, -2])[labels.long() != want.argmax(1)].max() < 1e-6)
