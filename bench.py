@@ -65,15 +65,28 @@ def make_frames(n_frames, seq_seed, tta=True):
     return out
 
 
+def host_cores(share=16):
+    """Cores this process may really use: cgroup quota if one is set, else the affinity mask, capped at the
+    per-GPU CPU share of the box (16) -- oversubscribing the shared 256-thread host makes torch-CPU crawl."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, share))
+
+
 def cpu_baseline(frames, state_dict, n_timed):
     """The CPU restatement of the same path (oracle/, bit-/tolerance-pinned to the reference) on the host
     cores of this box: 1 warm-up + n_timed scans at the same shape."""
     from oracle import net_torch
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     net = net_torch.OracleNet(state_dict)
     memory = None

@@ -40,6 +40,14 @@ def load():
         raise RuntimeError(
             "streammos_amd: %s is missing -- the HIP kernels are not built. Run "
             "`python -m streammos_amd.build` (or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+    # The kernels must run on the SAME HIP runtime instance as torch (stream handles and device pointers are
+    # only meaningful inside one runtime).  torch bundles its own libamdhip64.so.7; loading it first makes the
+    # dynamic linker resolve this library's DT_NEEDED libamdhip64.so.7 to that already-loaded copy instead of
+    # /opt/rocm's, which would be a second, device-less runtime inside the process.
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.isfile(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
