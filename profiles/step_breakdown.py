@@ -1,0 +1,23 @@
+"""Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV (one steady-state step = the span between
+two consecutive smos::tta_argmax launches).  usage: python profiles/step_breakdown.py <kernel_trace.csv> [title]"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "tta_argmax" in r["Kernel_Name"]]
+a, b = idx[-3], idx[-2]
+step = rows[a + 1:b + 1]
+t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
+if len(sys.argv) > 2:
+    print("# " + sys.argv[2])
+print("# one steady-state step: wall %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
+agg = collections.defaultdict(lambda: [0, 0])
+for r in step:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[r["Kernel_Name"][:120]][0] += 1
+    agg[r["Kernel_Name"][:120]][1] += d
+print("# busy %.3f ms" % (sum(v[1] for v in agg.values()) / 1e6))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%9.1f us  x%3d  %s" % (v[1] / 1e3, v[0], k))
