@@ -13,20 +13,21 @@ _TOP_LEVEL = ("point_deep", "deep_point", "MultiScaleDeformableAttention", "defo
 
 
 def install(force=False):
-    """Register the mirror packages in ``sys.modules`` under the reference's top-level names."""
+    """Register the mirror packages -- and every sub-module of them -- in ``sys.modules`` under the
+    reference's top-level names.  Sub-modules are imported under their real (streammos_amd.refapi.*) names
+    first and then aliased, so their relative imports keep working whichever name they are reached by."""
+    import pkgutil
     for name in _TOP_LEVEL:
-        if name in sys.modules and not force:
-            mod = sys.modules[name]
-            if getattr(mod, "__smos_refapi__", False):
-                continue
+        mod = sys.modules.get(name)
+        if mod is not None and not getattr(mod, "__smos_refapi__", False) and not force:
             raise RuntimeError("refapi.install(): a different module named %r is already imported (%s); "
                                "install() must run before the reference's own packages are imported"
                                % (name, getattr(mod, "__file__", "?")))
-        mod = importlib.import_module(__name__ + "." + name)
-        sys.modules[name] = mod
-        # publish already-imported submodules too (e.g. point_deep.cuda_kernel, models.StreamMOS)
-        prefix = __name__ + "." + name + "."
-        for full, sub in list(sys.modules.items()):
-            if full.startswith(prefix) and sub is not None:
-                sys.modules[name + "." + full[len(prefix):]] = sub
+    here = sys.modules[__name__]
+    for info in pkgutil.walk_packages(here.__path__, prefix=__name__ + "."):
+        importlib.import_module(info.name)
+    prefix = __name__ + "."
+    for full, sub in list(sys.modules.items()):
+        if sub is not None and full.startswith(prefix) and full[len(prefix):].split(".")[0] in _TOP_LEVEL:
+            sys.modules[full[len(prefix):]] = sub
     return [sys.modules[n] for n in _TOP_LEVEL]

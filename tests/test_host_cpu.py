@@ -1,0 +1,186 @@
+"""CPU-only checks: the C ABI exports what include/*.h declares, the host-side mirror of the reference
+interface, the CPU twin of VoxelMaxPool, sequence sharding (incl. a world_size-2 gloo run)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from streammos_amd import _lib, preprocess, streaming, synth
+from tests import cases
+from tests.util import check_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smos_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    names = _declared("smos.h")
+    assert len(names) >= 10
+    lib = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU; no compute call is made
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.SIGNATURES) | {"smos_last_error"}
+    assert lib.smos_abi_version() == 1
+
+
+def test_cpu_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libsmos_cpu.so"))
+    for n in _declared("smos_cpu.h"):
+        assert hasattr(lib, n), n
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    from streammos_amd import ops
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.bilinear_gather(torch.zeros(1, 2, 4, 4), torch.zeros(1, 3, 2), (1.0, 1.0))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.tta_argmax(torch.zeros(2, 3, 5))
+    from streammos_amd.refapi import MultiScaleDeformableAttention as msda
+    with pytest.raises(RuntimeError, match="CPU"):
+        msda.ms_deform_attn_forward(torch.zeros(1, 4, 1, 2), torch.tensor([[2, 2]]), torch.tensor([0]),
+                                    torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1), 64)
+
+
+@pytest.mark.parametrize("name", sorted(cases.voxel_maxpool_cases()))
+def test_cpu_twin_voxel_maxpool_bit_exact(golden, name):
+    """deep_point.VoxelMaxPool on CPU tensors (the DataLoader-side use) -> libsmos_cpu.so."""
+    from streammos_amd.refapi import deep_point
+    g = golden("ops_voxel_maxpool")
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()[name]
+    f = torch.from_numpy(feat).unsqueeze(-1).requires_grad_(True)
+    y = deep_point.VoxelMaxPool(f, torch.from_numpy(ind).unsqueeze(-1), out_size, scale)
+    assert np.array_equal(y.detach().numpy(), g["vmp_%s_out" % name])
+    y.backward(torch.from_numpy(cases.grad_like(y.shape, name)))
+    assert np.array_equal(f.grad[..., 0].numpy(), g["vmp_%s_grad" % name])
+    y64 = deep_point.VoxelMaxPool(torch.from_numpy(feat).double().unsqueeze(-1), torch.from_numpy(ind).double().unsqueeze(-1),
+                                  out_size, scale)
+    assert np.array_equal(y64.numpy(), g["vmp_%s_out" % name].astype(np.float64))
+
+
+def test_pybind_named_shims_keep_the_reference_argument_lists():
+    from streammos_amd.refapi.point_deep import cpu_kernel
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()["basic"]
+    f, i = torch.from_numpy(feat).unsqueeze(-1), torch.from_numpy(ind).unsqueeze(-1)
+    out = torch.zeros((2, 3) + tuple(out_size))
+    idx = torch.full((2, 200), -1, dtype=torch.int64)
+    cpu_kernel.voxel_maxpooling_cpu_forward(f, i, out, idx, torch.tensor(out.shape), torch.tensor(out.stride()),
+                                            torch.tensor(out_size), torch.tensor(scale))
+    from oracle import ops_np
+    want, want_idx = ops_np.voxel_maxpool_fwd(feat, ind, out_size, scale)
+    assert np.array_equal(out.numpy(), want) and np.array_equal(idx.numpy(), want_idx)
+
+
+def test_attnet_state_dict_layout_is_the_reference_layout():
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    m = StreamMOS.AttNet(cfg.get_config()[2])
+    layout = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))["stage1"]
+    mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+    assert mine == layout
+    assert sum(p.numel() for p in m.parameters()) == 4367726
+    # the twice-registered Unbalance blocks share storage (reference quirk, multi_view_encoder.py:344-354)
+    sd = m.state_dict()
+    assert sd["bev_net.header_unbalance_conv.layer7x3.0.weight"].data_ptr() == sd["bev_net.header_bev.1.layer7x3.0.weight"].data_ptr()
+    m.load_state_dict(synth.seeded_state_dict(sd), strict=True)
+
+
+def test_attnet_module_graph_on_cpu_matches_reference_golden(golden, monkeypatch):
+    """The host-side graph (module wiring, CPU twin scatter, grid_sample gather) against the reference's
+    outputs; the GPU-only sampler is swapped for the debug torch formulation, as deformattn/test.py does."""
+    from streammos_amd.refapi import MultiScaleDeformableAttention as msda
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.deformattn.functions import ms_deform_attn_core_pytorch
+    from streammos_amd.refapi.models import StreamMOS
+    monkeypatch.setattr(msda, "ms_deform_attn_forward",
+                        lambda v, s, l, loc, w, step: ms_deform_attn_core_pytorch(v, s, loc, w))
+    g = golden("e2e")
+    m = StreamMOS.AttNet(cfg.get_config()[2]).eval()
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict()), strict=True)
+    memory = None
+    with torch.no_grad():
+        for i, batch in enumerate(cases.e2e_frames(2)):
+            check_inputs(g, "e2e_f%d_in_sha" % i, batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"])
+            tb = {k: torch.from_numpy(v).unsqueeze(0) for k, v in batch.items()}
+            pred, _, _, _, memory = m.infer(tb, i, memory)
+            ref = g["e2e_f%d_pred" % i]
+            assert np.abs(pred.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_refapi_install_publishes_reference_names():
+    code = ("import sys; sys.path.insert(0, %r); import streammos_amd.refapi as r; r.install(); "
+            "import deep_point, point_deep.cuda_kernel, point_deep.cpu_kernel, MultiScaleDeformableAttention; "
+            "from models import StreamMOS; from networks import backbone; from deformattn.modules import MSDeformAttn; "
+            "import config.StreamMOS as c; m = eval('StreamMOS.AttNet')(c.get_config()[2]); "
+            "print(len(m.state_dict()), deep_point.VoxelMaxPool.__module__)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "474"
+
+
+def test_vote_history_window_follows_the_reference():
+    assert streaming.vote_history_ids(8) == [7, 6, 5, 4, 3, 2, 1, 0]       # voxel_voting.py:182
+    assert streaming.vote_history_ids(20) == list(range(19, 11, -1))
+    assert streaming.vote_history_ids(0) == [1, 2, 3, 4, 5, 6, 7]           # :199-200 (future frames)
+    assert streaming.vote_history_ids(5) == [0, 1, 2, 3, 4, 6, 7]
+
+
+def test_window_indices_follow_dataloadval():
+    assert preprocess.window_indices(0, 100, 3) == [0, 1, 2]
+    assert preprocess.window_indices(1, 100, 3) == [1, 2, 3]
+    assert preprocess.window_indices(2, 100, 3) == [2, 1, 0]
+    assert preprocess.window_indices(50, 100, 3) == [50, 49, 48]
+
+
+def test_shard_sequences_is_balanced_and_complete():
+    # SemanticKITTI test sequences 11-21 (scan counts), SURVEY.md section 8d config 4
+    lengths = {11: 921, 12: 1061, 13: 3281, 14: 631, 15: 1901, 16: 1731, 17: 491, 18: 1801, 19: 4981, 20: 831, 21: 2721}
+    shards = streaming.shard_sequences(lengths, 8)
+    assert sorted(s for sh in shards for s in sh) == sorted(lengths)
+    loads = [sum(lengths[s] for s in sh) for sh in shards]
+    assert max(loads) == 4981                      # bounded by the longest sequence
+    assert streaming.shard_sequences(lengths, 1) == [sorted(lengths, key=lambda k: -lengths[k])]
+
+
+_GLOO_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from streammos_amd import streaming
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lengths = {11: 921, 12: 1061, 13: 3281, 14: 631, 15: 1901}
+mine = streaming.shard_sequences(lengths, world)[rank]
+# every rank streams only its own sequences; the only exchange is the final gather of per-sequence counts
+done = torch.zeros(32, dtype=torch.int64)
+for s in mine:
+    done[s] = lengths[s]
+dist.all_reduce(done)
+elapsed = torch.tensor([1.0 + rank], dtype=torch.float64)
+dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps({"total": int(done.sum()), "max_elapsed": float(elapsed), "world": world}))
+dist.destroy_process_group()
+"""
+
+
+def test_sequence_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"total": 921 + 1061 + 3281 + 631 + 1901, "max_elapsed": 2.0, "world": 2}
