@@ -133,6 +133,37 @@ int smos_vote_resolve(const float* pts, int64_t n, int64_t pt_stride, const uint
                       int32_t recip_quantize, const uint64_t* table, const int32_t* lut,
                       int32_t* out_labels, smos_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Fused elementwise epilogues of the encoder (inference: BatchNorm scale folded into the conv weights on
+ * the host, so every conv -> BN -> ReLU (-> add -> ReLU) chain of the reference collapses into one
+ * pass).  All tensors float32; a "plane" is one contiguous (batch, channel) H*W slab, addressed as
+ * base + b*stride_b + c*stride_c (element strides), which lets an output land inside a channel slice of a
+ * concatenation buffer.
+ */
+/* out = act(x + bias[c] (+ res)); act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  bias / res may be NULL.
+ * Replaces BN+ReLU after a conv (networks/backbone.py:136-159, multi_view_encoder.py:460-497). */
+int smos_bias_act(const float* x, int64_t xs_b, int64_t xs_c, const float* bias, const float* res, int64_t rs_b,
+                  int64_t rs_c, float* out, int64_t os_b, int64_t os_c, int64_t B, int64_t C, int64_t HW,
+                  int32_t act, smos_stream_t stream);
+/* DownSample2D tail (networks/backbone.py:29-34): out = relu(a + bias[c] + maxpool3x3(p; stride, pad 1)).
+ * a [B,C,Ho,Wo] and p [B,C,H,W] with full element strides (NCHW or channels-last); out planes contiguous. */
+int smos_downsample_epilogue(const float* a, const int64_t* a_stride, const float* p, const int64_t* p_stride,
+                             const float* bias, float* out, int64_t os_b, int64_t os_c, int64_t B, int64_t C,
+                             int64_t H, int64_t W, int32_t stride, smos_stream_t stream);
+/* BasicBlock tail with ChannelAtt (networks/backbone.py:87-102,151-159):
+ * g = sigmoid(w2 * relu(w1 * mean_hw(y + bias) + b1) + b2); out = relu((y + bias) * g + xres).
+ * w1 [Cr,C], w2 [C,Cr] (the 1x1 conv weights), sums_ws: device scratch of B*C floats. */
+int smos_channel_gate_residual(const float* y, int64_t ys_b, int64_t ys_c, const float* bias, const float* w1,
+                               const float* b1, const float* w2, const float* b2, const float* xres, int64_t rs_b,
+                               int64_t rs_c, float* out, int64_t os_b, int64_t os_c, float* sums_ws, int64_t B,
+                               int64_t C, int64_t Cr, int64_t HW, smos_stream_t stream);
+/* Decoder input (networks/multi_view_encoder.py:441-447): bilinear resize (align_corners=True) of up to three
+ * NCHW maps to (Ho, Wo), concatenated along channels into out [B, sum C_i, Ho, Wo] (contiguous).
+ * src[i]: device pointers (host array), per-source C/H/W and batch/channel strides (host arrays). */
+int smos_upsample_concat(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
+                         const int64_t* src_sb, const int64_t* src_sc, int32_t n_src, float* out, int64_t B,
+                         int64_t Ho, int64_t Wo, smos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

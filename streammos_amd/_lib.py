@@ -27,6 +27,10 @@ SIGNATURES = {
     "smos_vote_clear": [vp, vp],
     "smos_vote_accumulate": [vp, i64, i64, vp, c_f64p, i32, vp, vp],
     "smos_vote_resolve": [vp, i64, i64, vp, i32, vp, vp, vp, vp],
+    "smos_bias_act": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i64, i64, i64, i32, vp],
+    "smos_downsample_epilogue": [vp, c_i64p, vp, c_i64p, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
+    "smos_channel_gate_residual": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, vp],
+    "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }
 
 _lib = None

@@ -1,0 +1,256 @@
+"""Fused inference engine for ``AttNet`` (eval mode, fp32, one GPU).
+
+``AttNet.infer`` / ``stage_forward`` keep the reference's module graph for training and for CPU
+tensors; on a GPU in eval mode they hand over to this engine, which computes the same function
+(models/StreamMOS.py:86-113, networks/multi_view_encoder.py:390-458) with far fewer passes over HBM:
+
+* BatchNorm is folded into the preceding conv's weights once (float64 on the host); what is left of
+  every conv -> BN -> ReLU (-> add -> ReLU) chain is one fused epilogue kernel (csrc/epilogue.hip);
+* concatenations never run: producers write straight into channel slices of the destination buffer
+  (conv epilogues, scatters and gathers all take output strides);
+* the three bilinear resizes + ``torch.cat`` in front of ``conv_1`` are one kernel;
+* the convs themselves stay on PyTorch-ROCm / MIOpen (NCHW Winograd kernels).
+
+The engine holds *copies* of the folded weights: it is rebuilt whenever the module's parameters may have
+changed (``load_state_dict``, ``.to()``, ``.train()``), see ``AttNet._engine_for``.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+RELU, LEAKY, NONE = ops.ACT_RELU, ops.ACT_LEAKY, ops.ACT_NONE
+
+
+def _fold(conv_w, conv_b, bn, pre=None):
+    """(w', b') with BatchNorm `bn` (eval statistics) applied AFTER the conv and, optionally, a BatchNorm
+    `pre` applied BEFORE it (PointNet's input BN, networks/backbone.py:205-210)."""
+    w = conv_w.detach().double()
+    b = conv_b.detach().double() if conv_b is not None else torch.zeros(w.shape[0], dtype=torch.float64, device=w.device)
+    if pre is not None:
+        s_in = pre.weight.detach().double() / torch.sqrt(pre.running_var.detach().double() + pre.eps)
+        o_in = pre.bias.detach().double() - pre.running_mean.detach().double() * s_in
+        b = b + (w.flatten(2).sum(2) * o_in[None, :]).sum(1)
+        w = w * s_in[None, :, None, None]
+    if bn is not None:
+        s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * s[:, None, None, None]
+        b = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+    return w.float().contiguous(), b.float().contiguous()
+
+
+class _Obj:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class InferenceEngine:
+    def __init__(self, net):
+        from .refapi.networks import backbone as bb
+        from .refapi.networks import multi_view_encoder as mve
+        self.device = next(net.parameters()).device
+        self.bev_hw = tuple(net.bev_wl_shape)
+        self._bb, self._mve = bb, mve
+        enc = net.bev_net
+
+        l0, l1 = net.point_pre.layer[0].layer, net.point_pre.layer[1].layer
+        self.pp1 = _fold(l0[1].weight, None, l0[2], pre=l0[0])
+        self.pp2 = _fold(l1[0].weight, None, l1[1])
+
+        self.header_bev = [self._block(m) for m in enc.header_bev]
+        self.header_rv = [self._block(m) for m in enc.header_rv]
+        self.res1_bev = [self._block(m) for m in enc.res1_bev]
+        self.res1_rv = [self._block(m) for m in enc.res1_rv]
+        self.res2 = [self._block(m) for m in enc.res2]
+
+        self.query_embed = enc.query_embed.weight.detach()
+        self.layers = []
+        for lyr in enc.deformattn_module.deformattn_layers:
+            ca = lyr.cross_attn
+            self.layers.append(_Obj(
+                heads=ca.n_heads, points=ca.n_points,
+                value=(ca.value_proj.weight.detach(), ca.value_proj.bias.detach()),
+                # one GEMM for offsets and attention logits
+                qproj=(torch.cat((ca.sampling_offsets.weight.detach(), ca.attention_weights.weight.detach()), 0).contiguous(),
+                       torch.cat((ca.sampling_offsets.bias.detach(), ca.attention_weights.bias.detach()), 0).contiguous()),
+                out=(ca.output_proj.weight.detach(), ca.output_proj.bias.detach()),
+                norm1=(lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), lyr.norm1.eps),
+                lin1=(lyr.linear1.weight.detach(), lyr.linear1.bias.detach()),
+                lin2=(lyr.linear2.weight.detach(), lyr.linear2.bias.detach()),
+                norm2=(lyr.norm2.weight.detach(), lyr.norm2.bias.detach(), lyr.norm2.eps)))
+
+        self.conv_1 = _fold(enc.conv_1.conv.weight, None, enc.conv_1.bn)
+        self.conv_2 = _fold(enc.conv_2.conv.weight, None, enc.conv_2.bn)
+        # the three 1x1 aux heads as ONE block-diagonal 1x1 conv over the 320-channel decoder input
+        heads = (enc.aux_head1, enc.aux_head2, enc.aux_head3)
+        ncls = heads[0].weight.shape[0]
+        cin = [h.weight.shape[1] for h in heads]
+        w = torch.zeros((3 * ncls, sum(cin), 1, 1), device=self.device)
+        off = 0
+        for i, h in enumerate(heads):
+            w[i * ncls:(i + 1) * ncls, off:off + cin[i]] = h.weight.detach()
+            off += cin[i]
+        self.aux = (w.contiguous(), torch.cat([h.bias.detach() for h in heads]).contiguous(), ncls)
+        self.grid2point_scale = tuple(net.bev_grid2point.scale_rate)
+
+        m = net.point_post.merge_layer
+        self.post1 = _fold(m[0].weight, None, m[1])
+        self.post2 = _fold(m[3].weight, None, m[4])
+        p = net.pred_layer.pred_layer[0]
+        self.pred = (p.weight.detach().contiguous(), p.bias.detach().contiguous())
+        self.sums_ws = torch.zeros(4096, dtype=torch.float32, device=self.device)
+        self._shapes = None
+        self._lsi = None
+
+    # ---- parameter extraction -----------------------------------------------------------
+    def _block(self, m):
+        bb, mve = self._bb, self._mve
+        if isinstance(m, bb.DownSample2D):
+            wa, ba = _fold(m.conv_branch[0].weight, None, m.conv_branch[1])
+            wp, bp = _fold(m.pool_branch[0].weight, None, m.pool_branch[1])
+            # maxpool(y + b) == maxpool(y) + b for a per-channel constant b: both biases move behind the pool
+            return _Obj(kind="down", wa=wa, wp=wp, bias=(ba + bp).contiguous(), stride=m.conv_branch[0].stride[0])
+        if isinstance(m, mve.Unbalance_BasicBlock):
+            wa, ba = _fold(m.layer7x3[0].weight, None, m.layer7x3[1])
+            wb, bb_ = _fold(m.layer3x7[0].weight, None, m.layer3x7[1])
+            wc, bc = _fold(m.layer3x3[0].weight, None, m.layer3x3[1])
+            return _Obj(kind="unbalance", wa=wa, ba=ba, pa=m.layer7x3[0].padding, wb=wb, bb=bb_, pb=m.layer3x7[0].padding,
+                        wc=wc, bc=bc)
+        if isinstance(m, bb.BasicBlock):
+            w1, b1 = _fold(m.layer[0].weight, None, m.layer[1])
+            w2, b2 = _fold(m.layer[3].weight, None, m.layer[4])
+            o = _Obj(kind="basic", w1=w1, b1=b1, w2=w2, b2=b2, att=m.use_att)
+            if m.use_att:
+                c1, c2 = m.channel_att.cnet[1], m.channel_att.cnet[3]
+                o.cw1 = c1.weight.detach().reshape(c1.weight.shape[0], -1).contiguous()
+                o.cb1 = c1.bias.detach().contiguous()
+                o.cw2 = c2.weight.detach().reshape(c2.weight.shape[0], -1).contiguous()
+                o.cb2 = c2.bias.detach().contiguous()
+            return o
+        raise RuntimeError("InferenceEngine: unexpected module %s" % type(m).__name__)
+
+    # ---- blocks ---------------------------------------------------------------------------
+    def _run_block(self, x, p, out=None):
+        if p.kind == "down":
+            a = F.conv2d(x, p.wa, None, p.stride, 1)
+            q = F.conv2d(x, p.wp)
+            return ops.downsample_epilogue(a, q, p.bias, p.stride, out=out if out is not None else a)
+        if p.kind == "unbalance":
+            b, c, h, w = x.shape
+            both = torch.empty((b, 2 * c, h, w), dtype=x.dtype, device=x.device)
+            ops.bias_act(F.conv2d(x, p.wa, None, 1, p.pa), p.ba, RELU, out=both[:, :c])
+            ops.bias_act(F.conv2d(x, p.wb, None, 1, p.pb), p.bb, RELU, out=both[:, c:])
+            y = F.conv2d(both, p.wc, None, 1, 1)
+            return ops.bias_act(y, p.bc, RELU, out=out if out is not None else y, residual=x)
+        y = F.conv2d(x, p.w1, None, 1, 1)
+        ops.bias_act(y, p.b1, RELU, out=y)
+        y2 = F.conv2d(y, p.w2, None, 1, 1)
+        dst = out if out is not None else y2
+        if p.att:
+            if y2.shape[0] * y2.shape[1] > self.sums_ws.numel():
+                self.sums_ws = torch.zeros(y2.shape[0] * y2.shape[1], dtype=torch.float32, device=y2.device)
+            return ops.channel_gate_residual(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.sums_ws, out=dst)
+        return ops.bias_act(y2, p.b2, RELU, out=dst, residual=x)
+
+    def _run_stage(self, x, blocks, out=None):
+        for i, p in enumerate(blocks):
+            x = self._run_block(x, p, out if i == len(blocks) - 1 else None)
+        return x
+
+    def _cross_view(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_out=None):
+        """cat_buf[:, :c] holds the BEV feature; fills cat_buf[:, c:] with the range-view branch scattered back
+        (multi_view_encoder.py:395-405 / :410-420).  Returns the R2P point features [B, c, N]."""
+        bev = cat_buf[:, :c]
+        b, n = bev_xy.shape[0], bev_xy.shape[1]
+        pts = ops.bilinear_gather(bev, bev_xy, scale)
+        rv = torch.zeros((b, c) + rv_hw, dtype=torch.float32, device=bev.device)
+        ops.voxel_maxpool_fwd(pts, sphere, rv, rv_hw, scale)
+        rv = self._run_stage(rv, rv_blocks)
+        pts = ops.bilinear_gather(rv, sphere, scale, out=point_out)
+        back = cat_buf[:, c:]
+        back.zero_()
+        ops.voxel_maxpool_fwd(pts, bev_xy, back, tuple(back.shape[2:]), scale)
+        return pts
+
+    def _temporal_fusion(self, x2, memory):
+        """DeformAttnModule (multi_view_encoder.py:426-439, 245-321): the memory stream queries the current map."""
+        b, c, hh, ww = x2.shape
+        dev = x2.device
+        if self._shapes is None or self._shapes[0, 0].item() != hh:
+            self._shapes = torch.tensor([[hh, ww]], dtype=torch.long, device=dev)
+            self._lsi = torch.zeros((1,), dtype=torch.long, device=dev)
+            ys = (torch.arange(hh, dtype=torch.float32, device=dev) + 0.5) / hh
+            xs = (torch.arange(ww, dtype=torch.float32, device=dev) + 0.5) / ww
+            self._ref = torch.stack((xs[None, :].expand(hh, ww), ys[:, None].expand(hh, ww)), -1).reshape(1, hh * ww, 1, 1, 1, 2)
+            self._norm = torch.tensor([ww, hh], dtype=torch.float32, device=dev)
+        src = x2.flatten(2).transpose(1, 2)
+        if memory is None:
+            query = self.query_embed.unsqueeze(0).expand(b, -1, -1)
+        else:
+            query = memory.flatten(2).transpose(1, 2)
+        lq = hh * ww
+        for L in self.layers:
+            h, p = L.heads, L.points
+            value = F.linear(src, *L.value).view(b, lq, h, c // h)
+            qp = F.linear(query, *L.qproj)
+            off = qp[..., :h * p * 2].reshape(b, lq, h, 1, p, 2)
+            attn = F.softmax(qp[..., h * p * 2:].reshape(b, lq, h, p), -1).view(b, lq, h, 1, p)
+            loc = (self._ref + off / self._norm).contiguous()
+            sampled = ops.msda_fwd(value.contiguous(), self._shapes, self._lsi, loc, attn.contiguous())
+            query = F.layer_norm(query + F.linear(sampled, *L.out), (c,), *L.norm1)
+            ffn = F.linear(F.relu(F.linear(query, *L.lin1)), *L.lin2)
+            query = F.layer_norm(query + ffn, (c,), *L.norm2)
+        return query.transpose(1, 2).reshape(b, c, hh, ww).contiguous()
+
+    # ---- the network ------------------------------------------------------------------------
+    @torch.no_grad()
+    def stage_forward(self, point_feat, pcds_coord, pcds_sphere_coord, memory=None):
+        bs, t, cin, n, _ = point_feat.shape
+        dev = point_feat.device
+        bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
+        sphere = pcds_sphere_coord[:, 0, :, :, 0].contiguous()
+
+        # point_pre (BN -> 1x1 -> BN -> ReLU -> 1x1 -> BN -> ReLU), then the input scatter
+        x = point_feat.reshape(bs * t, cin, n, 1).float()
+        h = F.conv2d(x, self.pp1[0])
+        ops.bias_act(h, self.pp1[1], RELU, out=h)
+        pts = F.conv2d(h, self.pp2[0])
+        ops.bias_act(pts, self.pp2[1], RELU, out=pts)
+        cpt = pts.shape[1]
+        hb, wb = self.bev_hw
+        bev = torch.zeros((bs * t, cpt, hb, wb), dtype=torch.float32, device=dev)
+        ops.voxel_maxpool_fwd(pts, pcds_coord.reshape(bs * t, n, 3)[:, :, :2].contiguous(), bev, (hb, wb), (1.0, 1.0))
+        bev = bev.view(bs, t * cpt, hb, wb)
+
+        c0 = self.header_bev[-1].w2.shape[0]
+        x0cat = torch.empty((bs, 2 * c0, hb // 2, wb // 2), dtype=torch.float32, device=dev)
+        self._run_stage(bev, self.header_bev, out=x0cat[:, :c0])
+        self._cross_view(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
+
+        c1 = self.res1_bev[-1].w2.shape[0]
+        x1cat = torch.empty((bs, 2 * c1, hb // 4, wb // 4), dtype=torch.float32, device=dev)
+        self._run_stage(x0cat, self.res1_bev, out=x1cat[:, :c1])
+        # point-wise fusion input [pts(t=0) | bev gather | range-view gather] assembled in place, never cat-ed
+        fuse = torch.empty((bs, cpt + self.conv_2[0].shape[0] + c1, n, 1), dtype=torch.float32, device=dev)
+        o1, o2 = cpt, cpt + self.conv_2[0].shape[0]
+        self._cross_view(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_out=fuse[:, o2:, :, 0])
+
+        x2 = self._run_stage(x1cat, self.res2)
+        x2 = self._temporal_fusion(x2, memory)
+
+        dec_in = ops.upsample_concat([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
+        y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
+        ops.bias_act(y, self.conv_1[1], LEAKY, out=y)
+        bev_feat = F.conv2d(y, self.conv_2[0], None, 1, 1)
+        ops.bias_act(bev_feat, self.conv_2[1], LEAKY, out=bev_feat)
+        aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
+        k = self.aux[2]
+
+        ops.bilinear_gather(bev_feat, bev_xy, self.grid2point_scale, out=fuse[:, o1:o2, :, 0])
+        fuse[:, :o1].copy_(pts.view(bs, t, cpt, n, 1)[:, 0])
+        z = F.conv2d(fuse, self.post1[0])
+        ops.bias_act(z, self.post1[1], RELU, out=z)
+        z = F.conv2d(z, self.post2[0])
+        ops.bias_act(z, self.post2[1], RELU, out=z)
+        pred = F.conv2d(z, self.pred[0], self.pred[1])
+        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2

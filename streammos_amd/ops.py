@@ -178,3 +178,88 @@ def vote_resolve(points, labels, table, lut=None, recip_quantize=False):
                                    lut.data_ptr() if lut is not None else None, out.data_ptr(), _stream(points))
     _lib.check(rc, "smos_vote_resolve")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# fused encoder epilogues (inference engine)
+# ---------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _planes(name, t):
+    """(batch stride, channel stride, H*W) of a 4-D tensor whose (H, W) planes are contiguous."""
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+        raise RuntimeError("%s: expected contiguous (H, W) planes, got shape %s strides %s" % (name, tuple(t.shape), t.stride()))
+    return t.stride(0), t.stride(1), t.shape[2] * t.shape[3]
+
+
+def bias_act(x, bias, act, out=None, residual=None):
+    """out = act(x + bias[c] (+ residual)); x, residual, out: [B,C,H,W] with contiguous planes (out may be a
+    channel slice of a larger buffer, or x itself)."""
+    _require_cuda("bias_act", x, bias, out, residual)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    xb, xc, hw = _planes("bias_act", x)
+    ob, oc, _ = _planes("bias_act", out)
+    rb = rc = 0
+    if residual is not None:
+        rb, rc, _ = _planes("bias_act", residual)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc_ = lib.smos_bias_act(x.data_ptr(), xb, xc, bias.data_ptr() if bias is not None else None,
+                                residual.data_ptr() if residual is not None else None, rb, rc, out.data_ptr(), ob, oc,
+                                x.shape[0], x.shape[1], hw, act, _stream(x))
+    _lib.check(rc_, "smos_bias_act")
+    return out
+
+
+def downsample_epilogue(a, p, bias, stride, out=None):
+    """relu(a + bias[c] + maxpool3x3(p, stride, pad 1)); a [B,C,Ho,Wo], p [B,C,H,W] any strides."""
+    _require_cuda("downsample_epilogue", a, p, bias, out)
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    ob, oc, _ = _planes("downsample_epilogue", out)
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        rc = lib.smos_downsample_epilogue(a.data_ptr(), _lib.i64_array(a.stride()), p.data_ptr(), _lib.i64_array(p.stride()),
+                                          bias.data_ptr(), out.data_ptr(), ob, oc, p.shape[0], p.shape[1], p.shape[2],
+                                          p.shape[3], stride, _stream(a))
+    _lib.check(rc, "smos_downsample_epilogue")
+    return out
+
+
+def channel_gate_residual(y, bias, w1, b1, w2, b2, xres, sums_ws, out=None):
+    _require_cuda("channel_gate_residual", y, bias, w1, b1, w2, b2, xres, sums_ws, out)
+    if out is None:
+        out = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    yb, yc, hw = _planes("channel_gate_residual", y)
+    rb, rc, _ = _planes("channel_gate_residual", xres)
+    ob, oc, _ = _planes("channel_gate_residual", out)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        rc_ = lib.smos_channel_gate_residual(y.data_ptr(), yb, yc, bias.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                             w2.data_ptr(), b2.data_ptr(), xres.data_ptr(), rb, rc, out.data_ptr(), ob, oc,
+                                             sums_ws.data_ptr(), y.shape[0], y.shape[1], w1.shape[0], hw, _stream(y))
+    _lib.check(rc_, "smos_channel_gate_residual")
+    return out
+
+
+def upsample_concat(sources, size, out=None):
+    """Bilinear (align_corners=True) resize of up to three [B,C_i,H_i,W_i] maps to `size`, concatenated along C."""
+    import ctypes
+    _require_cuda("upsample_concat", *sources)
+    b = sources[0].shape[0]
+    ctot = sum(s.shape[1] for s in sources)
+    if out is None:
+        out = torch.empty((b, ctot, size[0], size[1]), dtype=torch.float32, device=sources[0].device)
+    strides = [_planes("upsample_concat", s) for s in sources]
+    ptrs = (ctypes.c_void_p * len(sources))(*[s.data_ptr() for s in sources])
+    lib = _lib.load()
+    with torch.cuda.device(out.device):
+        rc = lib.smos_upsample_concat(ptrs, _lib.i64_array([s.shape[1] for s in sources]),
+                                      _lib.i64_array([s.shape[2] for s in sources]),
+                                      _lib.i64_array([s.shape[3] for s in sources]),
+                                      _lib.i64_array([st[0] for st in strides]), _lib.i64_array([st[1] for st in strides]),
+                                      len(sources), out.data_ptr(), b, size[0], size[1], _stream(out))
+    _lib.check(rc, "smos_upsample_concat")
+    return out

@@ -36,6 +36,7 @@ class AttNet(nn.Module):
         self.dz = (vox.range_z[1] - vox.range_z[0]) / vox.bev_shape[2]
         self.point_feat_out_channels = pModel.point_feat_out_channels
         self.build_network()
+        self.fast_inference = True      # eval-mode GPU inference runs the fused engine (streammos_amd/engine.py)
         self._engine = None
 
     def build_network(self):
@@ -52,11 +53,40 @@ class AttNet(nn.Module):
                                  out_channel=self.point_feat_out_channels)
         self.pred_layer = backbone.PredBranch(self.point_feat_out_channels, p.class_num)
 
+    # ---- fused inference engine: holds folded copies of the weights, so anything that may change the
+    # parameters (or the module tree) drops it; it is rebuilt lazily on the next eval-mode GPU call
+    def invalidate_engine(self):
+        self._engine = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._engine = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        self._engine = None
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _engine_for(self, tensor):
+        if not self.fast_inference or self.training or not tensor.is_cuda or torch.is_grad_enabled():
+            return None
+        if self._engine is None or self._engine.device != tensor.device:
+            from ... import engine
+            self._engine = engine.InferenceEngine(self)
+        return self._engine
+
     # ------------------------------------------------------------------------------------
     def stage_forward(self, point_feat, pcds_coord, pcds_sphere_coord, query_embed_store=None, use_query_store=False,
                       return_query=False):
         """point_feat (BS,T,C,N,1), pcds_coord (BS,T,N,3,1), pcds_sphere_coord (BS,T,N,2,1)
         -> pred_cls (BS,class_num,N,1), three BEV aux maps, new memory (BS,128,64,64)   [StreamMOS.py:86-113]"""
+        eng = self._engine_for(point_feat)
+        if eng is not None:
+            return eng.stage_forward(point_feat, pcds_coord, pcds_sphere_coord,
+                                     query_embed_store if use_query_store else None)
         bs, t, c, n, _ = point_feat.shape
         cur_xy = pcds_coord[:, 0, :, :2].contiguous()
         cur_sphere = pcds_sphere_coord[:, 0].contiguous()

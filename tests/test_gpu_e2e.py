@@ -93,3 +93,85 @@ def test_model_survives_reference_val_wrapping(model):
         a = m.infer(tb, 0)[0]
         b = model.infer(tb, 0)[0]
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+
+
+def test_fused_engine_equals_module_graph(model):
+    """The fused engine (folded BN, fused epilogues, no concatenations) against the plain module graph with the
+    same weights on the same GPU: identical function, differences only from BN folding / summation order."""
+    frames = list(cases.e2e_frames(2))
+    outs = {}
+    for fast in (False, True):
+        model.fast_inference = fast
+        memory = None
+        res = []
+        with torch.no_grad():
+            for i, batch in enumerate(frames):
+                tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+                pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+                res.append((pred, a0, a1, a2, memory))
+        outs[fast] = res
+    model.fast_inference = True
+    assert model._engine is not None
+    for slow, fast in zip(outs[False], outs[True]):
+        for a, b in zip(slow, fast):
+            assert a.shape == b.shape
+            assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
+
+
+def test_engine_is_dropped_when_weights_change(model):
+    import copy
+    m = copy.deepcopy(model)
+    batch = next(iter(cases.e2e_frames(1)))
+    tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        a = m.infer(tb, 0)[0]
+        assert m._engine is not None
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["pred_layer.pred_layer.0.bias"] += 1.0
+        m.load_state_dict(sd)
+        assert m._engine is None
+        b = m.infer(tb, 0)[0]
+    assert abs((b - a).mean().item() - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["bias_act", "downsample", "gate", "upsample"])
+def test_epilogue_kernels_against_torch(name):
+    import torch.nn.functional as F
+    from streammos_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    if name == "bias_act":
+        x, res, bias = r(3, 8, 20, 12), r(3, 16, 20, 12), r(8)
+        big = torch.zeros(3, 24, 20, 12, device=DEV)
+        for act, fn in ((0, lambda t: t), (1, torch.relu), (2, lambda t: F.leaky_relu(t, 0.01))):
+            ops.bias_act(x, bias, act, out=big[:, 8:16], residual=res[:, 4:12])
+            want = fn(x + bias[None, :, None, None] + res[:, 4:12])
+            assert torch.equal(big[:, 8:16], want) or (big[:, 8:16] - want).abs().max() < 1e-6
+            assert big[:, :8].abs().max() == 0 and big[:, 16:].abs().max() == 0
+        y = r(2, 3, 5, 7)                                  # odd plane size -> scalar path
+        assert (ops.bias_act(y, None, 1) - torch.relu(y)).abs().max() == 0
+    elif name == "downsample":
+        for stride, hw in ((2, (32, 48)), (1, (8, 64)), (2, (31, 17))):
+            p, bias = r(2, 5, *hw), r(5)
+            a = r(2, 5, (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1)
+            want = torch.relu(a + bias[None, :, None, None] + F.max_pool2d(p, 3, stride, 1))
+            got = ops.downsample_epilogue(a.clone(), p, bias, stride)
+            assert (got - want).abs().max() < 1e-6
+            got_cl = ops.downsample_epilogue(a.contiguous(memory_format=torch.channels_last),
+                                             p.contiguous(memory_format=torch.channels_last), bias, stride,
+                                             out=torch.empty_like(a))
+            assert (got_cl - want).abs().max() < 1e-6
+    elif name == "gate":
+        y, x, bias = r(2, 16, 12, 20), r(2, 16, 12, 20), r(16)
+        w1, b1, w2, b2 = r(4, 16), r(4), r(16, 4), r(16)
+        z = y + bias[None, :, None, None]
+        g = torch.sigmoid(F.linear(torch.relu(F.linear(z.mean((2, 3)), w1, b1)), w2, b2))
+        want = torch.relu(z * g[:, :, None, None] + x)
+        got = ops.channel_gate_residual(y, bias, w1, b1, w2, b2, x, torch.zeros(64, device=DEV))
+        assert (got - want).abs().max() < 1e-5
+    else:
+        a, b, c = r(2, 4, 16, 24), r(2, 6, 8, 12), r(2, 5, 4, 6)
+        want = torch.cat([F.interpolate(t, size=(16, 24), mode="bilinear", align_corners=True) for t in (a, b, c)], 1)
+        got = ops.upsample_concat([a, b, c], (16, 24))
+        assert torch.equal(got[:, :4], a)
+        assert (got - want).abs().max() < 1e-5
