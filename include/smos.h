@@ -164,6 +164,31 @@ int smos_upsample_concat(const float* const* src, const int64_t* src_c, const in
                          const int64_t* src_sb, const int64_t* src_sc, int32_t n_src, float* out, int64_t B,
                          int64_t Ho, int64_t Wo, smos_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Fused point-side kernels of the inference engine (csrc/point_fused.hip).  Scatter targets are
+ * channels-last and zero-filled by the caller; features are assumed >= 0 (post-ReLU), as on every call
+ * site of the model.
+ */
+/* point_pre + input scatter (models/StreamMOS.py:101-103): per-point MLP cin->cmid->cout (BatchNorm folded
+ * into w/b, ReLU after both layers; only 7->64->64 is built) on xyzi [B*T, cin, N], max-scattered into
+ * bev [B, H, W, T*cout] at cell (int(coord0), int(coord1)), coord [B*T, N, K].  pts_out (optional): the
+ * features of the t == 0 scan as rows pts_out[b*po_b + n*po_n + c]. */
+int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                          const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b, int64_t po_n,
+                          int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin, int32_t cmid,
+                          int32_t cout, smos_stream_t stream);
+/* BilinearSample (networks/backbone.py:453-475) of grid [B,C,Hg,Wg] (element strides grid_stride[4]) at
+ * gcoord*gscale, fused with VoxelMaxPool of the result into out [B,Ho,Wo,C] (channels-last) at
+ * int(scoord*sscale) (networks/multi_view_encoder.py:395-404,410-419).  out may be NULL (gather only);
+ * pts_out (optional) receives the gathered features as rows pts_out[b*po_b + n*po_n + c]. C % 32 == 0. */
+int smos_gather_scatter(const float* grid, const int64_t* grid_stride, const float* gcoord, int32_t Kg,
+                        const float* gscale, const float* scoord, int32_t Ks, const float* sscale, float* out,
+                        float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
+                        int64_t N, int64_t Ho, int64_t Wo, smos_stream_t stream);
+/* channels-last [B, HW, C] -> NCHW planes dst[b*ds_b + c*ds_c + p] (a channel slice of a larger buffer). */
+int smos_nhwc_to_nchw(const float* src, float* dst, int64_t ds_b, int64_t ds_c, int64_t B, int64_t C, int64_t HW,
+                      smos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,9 @@ SIGNATURES = {
     "smos_bias_act": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_downsample_epilogue": [vp, c_i64p, vp, c_i64p, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
     "smos_channel_gate_residual": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, vp],
+    "smos_pointnet_scatter": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
+    "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
+    "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }
 

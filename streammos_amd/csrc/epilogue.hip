@@ -94,6 +94,60 @@ __global__ __launch_bounds__(kBlock) void downsample_epilogue(const float* __res
   }
 }
 
+
+// Channels-last variant of downsample_epilogue: a [B,Ho,Wo,C] and p [B,H,W,C] are read with lane = channel
+// (contiguous C-float rows), the result is transposed through LDS and written as NCHW planes.
+// One block = one output row segment of 64 pixels x 32 channels.
+__global__ __launch_bounds__(kBlock) void downsample_epilogue_cl(const float* __restrict__ a, const float* __restrict__ p,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int64_t os_b, int64_t os_c, int C, int H, int W, int Ho,
+                                                                 int Wo, int stride) {
+  __shared__ float tile[32][65];
+  const int c_blocks = C / 32;
+  const int cb = blockIdx.y % c_blocks;
+  const int b = blockIdx.y / c_blocks;
+  const int seg_per_row = (Wo + 63) / 64;
+  const int ho = blockIdx.x / seg_per_row;
+  const int wo0 = (blockIdx.x - ho * seg_per_row) * 64;
+  const int c = cb * 32 + (threadIdx.x & 31);
+  const float bv = bias[c];
+  const float* ab = a + ((int64_t)b * Ho + ho) * Wo * C + c;
+  const float* pb = p + (int64_t)b * H * W * C + c;
+  const int h0 = ho * stride - 1;
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int px = pass * 8 + (threadIdx.x >> 5);
+    const int wo = wo0 + px;
+    float v = 0.0f;
+    if (wo < Wo) {
+      const int w0 = wo * stride - 1;
+      float m = -INFINITY;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int h = h0 + dy;
+        if (h < 0 || h >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int w = w0 + dx;
+          if (w < 0 || w >= W) continue;
+          m = fmaxf(m, pb[((int64_t)h * W + w) * C]);
+        }
+      }
+      v = fmaxf((ab[(int64_t)wo * C] + m) + bv, 0.0f);
+    }
+    tile[threadIdx.x & 31][px] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wo0 + lane < Wo) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int cc = wv * 8 + r;
+      out[(int64_t)b * os_b + (int64_t)(cb * 32 + cc) * os_c + (int64_t)ho * Wo + wo0 + lane] = tile[cc][lane];
+    }
+  }
+}
+
 // sums[b*C + c] = sum over the plane of x (one block per plane; float accumulation per thread, then a
 // wave shuffle + LDS reduction)
 __global__ __launch_bounds__(kBlock) void plane_sum(const float* __restrict__ x, int64_t xs_b, int64_t xs_c, int C,
@@ -239,6 +293,14 @@ extern "C" int smos_downsample_epilogue(const float* a, const int64_t* a_stride,
   for (int i = 0; i < 4; ++i) {
     as.v[i] = a_stride[i];
     ps.v[i] = p_stride[i];
+  }
+  const bool a_cl = a_stride[1] == 1 && a_stride[3] == C && a_stride[2] == (int64_t)Wo * C && a_stride[0] == (int64_t)Ho * Wo * C;
+  const bool p_cl = p_stride[1] == 1 && p_stride[3] == C && p_stride[2] == W * C && p_stride[0] == H * W * C;
+  if (a_cl && p_cl && C % 32 == 0) {
+    dim3 gcl((unsigned)(Ho * ((Wo + 63) / 64)), (unsigned)(B * (C / 32)));
+    hipLaunchKernelGGL(downsample_epilogue_cl, gcl, dim3(kBlock), 0, (hipStream_t)stream, a, p, bias, out, os_b, os_c, (int)C,
+                       (int)H, (int)W, Ho, Wo, (int)stride);
+    return check_launch("downsample_epilogue_cl");
   }
   dim3 grid((unsigned)((Ho * Wo + kBlock * 4 - 1) / (kBlock * 4)), (unsigned)(B * C));
   hipLaunchKernelGGL(downsample_epilogue, grid, dim3(kBlock), 0, (hipStream_t)stream, a, as, p, ps, bias, out, os_b, os_c,

@@ -1,0 +1,297 @@
+// Fused point-side kernels of the inference engine (gfx950).
+//
+//   pointnet_scatter : per-point MLP 7 -> 64 -> 64 (BatchNorm folded, ReLU) computed in registers and
+//                      max-scattered straight into the channels-last BEV grid -- the (BS*T, 64, N) feature
+//                      tensor of the reference (491 MB written by point_pre and read back by VoxelMaxPool,
+//                      models/StreamMOS.py:101-102) never exists.
+//   gather_scatter   : grid -> point bilinear gather fused with the point -> grid max scatter of the other
+//                      view (B2P -> P2R and R2P -> P2B, networks/multi_view_encoder.py:395-404,410-419);
+//                      optionally also emits the gathered point features (x1_point / the final
+//                      bev_grid2point output) in point-major rows.
+//   nhwc_to_nchw     : tiled transpose of a channels-last scatter target into a (strided) NCHW slice.
+//
+// Common structure ("LDS-staged accumulation"): phase 1 runs with lane = point, which is what the
+// per-point arithmetic and the coalesced reads of channel-major inputs want; the 64-point x 32-channel
+// result tile is staged in LDS (row pitch 36 floats: conflict-free for the 128-bit writes and the 32-bit
+// row reads); phase 2 runs with lane = channel, so every wave instruction is two contiguous 128-byte rows
+// (two points) -- the shape at which MI355X's memory-side atomics run at full rate -- instead of 64
+// scattered 4-byte atomics.  Values <= 0 are skipped against the zero-filled grid exactly as in
+// voxel_maxpool.hip (all of these features are post-ReLU or convex blends of post-ReLU maps).
+#include "smos_common.h"
+
+namespace smos {
+
+// Weights are wave-uniform: reading them through the constant address space makes hipcc emit scalar
+// loads (s_load_dwordx8/16 into SGPRs, consumed directly as the scalar operand of v_fmac) instead of
+// per-lane vector loads that would occupy the VGPR file.
+typedef const float __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)(uintptr_t)p; }
+
+constexpr int kTileP = 64;   // points per wave tile
+constexpr int kTileC = 32;   // channels per round
+constexpr int kPitch = 36;   // floats per LDS row
+
+__device__ __forceinline__ int cell_2d(const float* __restrict__ row, float sy, float sx, int H, int W) {
+  // same rule as voxel_maxpool.hip::cell_offset (reference: point_deep_cuda_kernel.cu:39-47)
+  const float py = __fmul_rn(row[0], sy), px = __fmul_rn(row[1], sx);
+  const bool ok = (py > -1.0f) && (py < (float)H) && (px > -1.0f) && (px < (float)W);
+  return ok ? (int)py * W + (int)px : -1;
+}
+
+// phase 2: lanes 0-31 take point 2i, lanes 32-63 point 2i+1; lane = channel
+__device__ __forceinline__ void rows_phase(const float* __restrict__ tile, const int* __restrict__ cells, int lane,
+                                           float* __restrict__ grid_base, int64_t cell_pitch, int ch0,
+                                           float* __restrict__ pts_base, int64_t po_n, int n_valid) {
+  const int c = lane & 31, half = lane >> 5;
+#pragma unroll 4
+  for (int i = 0; i < kTileP / 2; ++i) {
+    const int p = 2 * i + half;
+    const float v = tile[p * kPitch + c];
+    if (pts_base && p < n_valid) pts_base[(int64_t)p * po_n + ch0 + c] = v;
+    const int cell = cells[p];
+    if (grid_base && cell >= 0 && v > 0.0f)
+      atomicMax(reinterpret_cast<int*>(grid_base + (int64_t)cell * cell_pitch + ch0 + c), __float_as_int(v));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PointNet(7 -> 64 -> 64) + scatter
+// ---------------------------------------------------------------------------------------------
+struct PnsArgs {
+  const float* xyzi;   // [S, 7, N]
+  const float* coord;  // [S, N, K]
+  const float* w1;     // [64, 7]  (BN folded)
+  const float* b1;     // [64]
+  const float* w2;     // [64, 64]
+  const float* b2;     // [64]
+  float* bev;          // [B, H, W, T*64] zero-filled
+  float* pts_out;      // [B, N, *] rows of the t == 0 sample (row pitch po_n), or null
+  int64_t bev_sb, po_b, po_n;
+  int S, T, N, K, H, W, tiles_per_sample;
+};
+
+__global__ __launch_bounds__(kBlock, 4) void pointnet_scatter(PnsArgs a) {
+  __shared__ float lds_tile[kBlock / kWave][kTileP * kPitch];
+  __shared__ int lds_cell[kBlock / kWave][kTileP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n_tiles = (int64_t)a.S * a.tiles_per_sample;
+  // every wave of a block runs the same number of iterations (block-level barriers inside)
+  for (int64_t tile0 = (int64_t)blockIdx.x * (kBlock / kWave); tile0 < n_tiles; tile0 += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t tile = tile0 + wave;
+    const bool live = tile < n_tiles;
+    const int s = live ? (int)(tile / a.tiles_per_sample) : 0;
+    const int n0 = live ? (int)(tile - (int64_t)s * a.tiles_per_sample) * kTileP : 0;
+    const int n = n0 + lane;
+    const bool has = live && n < a.N;
+    const int b = s / a.T, t = s - b * a.T;
+
+    float x[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = has ? a.xyzi[((int64_t)s * 7 + j) * a.N + n] : 0.0f;
+    lds_cell[wave][lane] = has ? cell_2d(a.coord + ((int64_t)s * a.N + n) * a.K, 1.0f, 1.0f, a.H, a.W) : -1;
+
+    cfloat* w1 = as_const(a.w1);
+    cfloat* b1 = as_const(a.b1);
+    cfloat* w2 = as_const(a.w2);
+    cfloat* b2 = as_const(a.b2);
+    float h[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      float acc = b1[k];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc = fmaf(w1[k * 7 + j], x[j], acc);
+      h[k] = fmaxf(acc, 0.0f);
+    }
+    const int n_valid = live ? min(kTileP, a.N - n0) : 0;
+    float* grid_base = a.bev + (int64_t)b * a.bev_sb;
+    float* pts_base = (a.pts_out && t == 0 && live) ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n : nullptr;
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+      float* row = &lds_tile[wave][lane * kPitch];
+#pragma unroll
+      for (int j4 = 0; j4 < kTileC; j4 += 4) {
+        float y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = r * kTileC + j4 + u;
+          float acc = b2[j];
+#pragma unroll
+          for (int k = 0; k < 64; ++k) acc = fmaf(w2[j * 64 + k], h[k], acc);
+          y[u] = fmaxf(acc, 0.0f);
+        }
+        *reinterpret_cast<float4*>(row + j4) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+      __syncthreads();
+      if (live) rows_phase(lds_tile[wave], lds_cell[wave], lane, grid_base, (int64_t)a.T * 64, t * 64 + r * kTileC, pts_base,
+                           a.po_n, n_valid);
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear gather (NCHW or any-stride grid) -> [optional point rows] -> [optional max scatter, channels-last]
+// ---------------------------------------------------------------------------------------------
+struct GsArgs {
+  const float* grid;    // [B, C, Hg, Wg] element strides gs_*
+  const float* gcoord;  // [B, N, Kg]  gather coordinates
+  const float* scoord;  // [B, N, Ks]  scatter coordinates (or null)
+  float* out;           // [B, Ho, Wo, C] zero-filled channels-last scatter target (or null)
+  float* pts_out;       // [B, N, *] point rows (row pitch po_n, channel offset applied by the host) or null
+  int64_t gs_b, gs_c, gs_h, gs_w, out_sb, po_b, po_n;
+  int B, C, N, Kg, Ks, Hg, Wg, Ho, Wo, tiles_per_sample;
+  float gsy, gsx, ssy, ssx;
+};
+
+__device__ __forceinline__ float pix(float c, float s, int size) {
+  // networks/backbone.py:467-468 + ATen grid_sampler_unnormalize(align_corners=True); see bilinear_gather.hip
+  const float sm1 = (float)(size - 1);
+  const float gn = __fsub_rn(__fdiv_rn(__fmul_rn(__fmul_rn(2.0f, c), s), sm1), 1.0f);
+  return __fmul_rn(__fdiv_rn(__fadd_rn(gn, 1.0f), 2.0f), sm1);
+}
+
+__global__ __launch_bounds__(kBlock) void gather_scatter(GsArgs a) {
+  __shared__ float lds_tile[kBlock / kWave][kTileP * kPitch];
+  __shared__ int lds_cell[kBlock / kWave][kTileP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n_tiles = (int64_t)a.B * a.tiles_per_sample;
+  for (int64_t tile0 = (int64_t)blockIdx.x * (kBlock / kWave); tile0 < n_tiles; tile0 += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t tile = tile0 + wave;
+    const bool live = tile < n_tiles;
+    const int b = live ? (int)(tile / a.tiles_per_sample) : 0;
+    const int n0 = live ? (int)(tile - (int64_t)b * a.tiles_per_sample) * kTileP : 0;
+    const int n = n0 + lane;
+    const bool has = live && n < a.N;
+
+    int64_t off[4] = {-1, -1, -1, -1};
+    float wt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has) {
+      const float* cr = a.gcoord + ((int64_t)b * a.N + n) * a.Kg;
+      const float iy = pix(cr[0], a.gsy, a.Hg), ix = pix(cr[1], a.gsx, a.Wg);
+      const float fy = floorf(iy), fx = floorf(ix);
+      const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+      const bool fin = (iy > -2.0f) && (iy < (float)(a.Hg + 1)) && (ix > -2.0f) && (ix < (float)(a.Wg + 1));
+      const int y0 = fin ? (int)fy : -5, x0 = fin ? (int)fx : -5;
+      const float w4[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = y0 + (k >> 1), xx = x0 + (k & 1);
+        const bool in = (y >= 0) && (y < a.Hg) && (xx >= 0) && (xx < a.Wg);
+        off[k] = in ? (int64_t)y * a.gs_h + (int64_t)xx * a.gs_w : (int64_t)-1;
+        wt[k] = in ? w4[k] : 0.0f;
+      }
+    }
+    lds_cell[wave][lane] = (has && a.scoord) ? cell_2d(a.scoord + ((int64_t)b * a.N + n) * a.Ks, a.ssy, a.ssx, a.Ho, a.Wo) : -1;
+    const float* gb = a.grid + (int64_t)b * a.gs_b;
+    const int n_valid = live ? min(kTileP, a.N - n0) : 0;
+    float* grid_base = a.out ? a.out + (int64_t)b * a.out_sb : nullptr;
+    float* pts_base = (a.pts_out && live) ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n : nullptr;
+    for (int c0 = 0; c0 < a.C; c0 += kTileC) {
+      float* row = &lds_tile[wave][lane * kPitch];
+#pragma unroll 2
+      for (int j4 = 0; j4 < kTileC; j4 += 4) {
+        float y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* gc = gb + (int64_t)(c0 + j4 + u) * a.gs_c;
+          float acc = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (off[k] >= 0) acc += gc[off[k]] * wt[k];
+          y[u] = acc;
+        }
+        *reinterpret_cast<float4*>(row + j4) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+      __syncthreads();
+      if (live) rows_phase(lds_tile[wave], lds_cell[wave], lane, grid_base, (int64_t)a.C, c0, pts_base, a.po_n, n_valid);
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// channels-last [B, HW, C] -> NCHW slice (batch stride ds_b, channel stride ds_c, contiguous planes)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void nhwc_to_nchw(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                       int64_t HW, int64_t ds_b, int64_t ds_c) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* sp = src + (int64_t)b * HW * C;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t p = p0 + r;
+    const int c = c0 + tx;
+    t[r][tx] = (p < HW && c < C) ? sp[p * C + c] : 0.0f;
+  }
+  __syncthreads();
+  float* dp = dst + (int64_t)b * ds_b;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const int64_t p = p0 + tx;
+    if (p < HW && c < C) dp[(int64_t)c * ds_c + p] = t[tx][r];
+  }
+}
+
+}  // namespace smos
+
+using namespace smos;
+
+extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                     const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b,
+                                     int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                                     int32_t cmid, int32_t cout, smos_stream_t stream) {
+  if (cin != 7 || cmid != 64 || cout != 64) {
+    set_error("pointnet_scatter: built for the 7 -> 64 -> 64 point MLP (got %d -> %d -> %d)", (int)cin, (int)cmid, (int)cout);
+    return SMOS_ERR_UNSUPPORTED;
+  }
+  SMOS_REQUIRE(B > 0 && T > 0 && N > 0 && H > 0 && W > 0 && K >= 2, "pointnet_scatter: bad sizes");
+  SMOS_REQUIRE(xyzi && coord && w1 && b1 && w2 && b2 && bev, "pointnet_scatter: null pointer");
+  SMOS_REQUIRE(H * W < (1LL << 31) && (!pts_out || po_n >= 64), "pointnet_scatter: bad geometry");
+  PnsArgs a;
+  a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.pts_out = pts_out;
+  a.bev_sb = H * W * T * 64; a.po_b = po_b; a.po_n = po_n;
+  a.S = (int)(B * T); a.T = (int)T; a.N = (int)N; a.K = K; a.H = (int)H; a.W = (int)W;
+  a.tiles_per_sample = (int)((N + kTileP - 1) / kTileP);
+  const int64_t tiles = (int64_t)a.S * a.tiles_per_sample;
+  const int64_t blocks = (tiles + 3) / 4;
+  hipLaunchKernelGGL(pointnet_scatter, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(kBlock), 0,
+                     (hipStream_t)stream, a);
+  return check_launch("pointnet_scatter");
+}
+
+extern "C" int smos_gather_scatter(const float* grid, const int64_t* grid_stride, const float* gcoord, int32_t Kg,
+                                   const float* gscale, const float* scoord, int32_t Ks, const float* sscale, float* out,
+                                   float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
+                                   int64_t N, int64_t Ho, int64_t Wo, smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && C > 0 && C % kTileC == 0 && N > 0 && Hg > 0 && Wg > 0 && Kg >= 2, "gather_scatter: bad sizes (C must be a multiple of 32)");
+  SMOS_REQUIRE(grid && grid_stride && gcoord && gscale, "gather_scatter: null pointer");
+  SMOS_REQUIRE(out || pts_out, "gather_scatter: nothing to produce");
+  SMOS_REQUIRE(!out || (scoord && sscale && Ks >= 2 && Ho > 0 && Wo > 0 && Ho * Wo < (1LL << 31)), "gather_scatter: bad scatter target");
+  SMOS_REQUIRE(!pts_out || po_n >= C, "gather_scatter: point row pitch smaller than C");
+  GsArgs a;
+  a.grid = grid; a.gcoord = gcoord; a.scoord = out ? scoord : nullptr; a.out = out; a.pts_out = pts_out;
+  a.gs_b = grid_stride[0]; a.gs_c = grid_stride[1]; a.gs_h = grid_stride[2]; a.gs_w = grid_stride[3];
+  a.out_sb = Ho * Wo * C; a.po_b = po_b; a.po_n = po_n;
+  a.B = (int)B; a.C = (int)C; a.N = (int)N; a.Kg = Kg; a.Ks = Ks; a.Hg = (int)Hg; a.Wg = (int)Wg; a.Ho = (int)Ho; a.Wo = (int)Wo;
+  a.tiles_per_sample = (int)((N + kTileP - 1) / kTileP);
+  a.gsy = gscale[0]; a.gsx = gscale[1];
+  a.ssy = out ? sscale[0] : 0.f; a.ssx = out ? sscale[1] : 0.f;
+  const int64_t tiles = B * a.tiles_per_sample;
+  const int64_t blocks = (tiles + 3) / 4;
+  hipLaunchKernelGGL(gather_scatter, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(kBlock), 0,
+                     (hipStream_t)stream, a);
+  return check_launch("gather_scatter");
+}
+
+extern "C" int smos_nhwc_to_nchw(const float* src, float* dst, int64_t ds_b, int64_t ds_c, int64_t B, int64_t C, int64_t HW,
+                                 smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && C > 0 && HW > 0 && src && dst, "nhwc_to_nchw: bad arguments");
+  SMOS_REQUIRE(B <= 65535 && (C + 31) / 32 <= 65535, "nhwc_to_nchw: too many batches / channels");
+  dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(nhwc_to_nchw, grid, dim3(kBlock), 0, (hipStream_t)stream, src, dst, (int)C, HW, ds_b, ds_c);
+  return check_launch("nhwc_to_nchw");
+}

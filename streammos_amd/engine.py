@@ -46,11 +46,8 @@ class _Obj:
 
 class InferenceEngine:
     def __init__(self, net):
-        from .refapi.networks import backbone as bb
-        from .refapi.networks import multi_view_encoder as mve
         self.device = next(net.parameters()).device
         self.bev_hw = tuple(net.bev_wl_shape)
-        self._bb, self._mve = bb, mve
         enc = net.bev_net
 
         l0, l1 = net.point_pre.layer[0].layer, net.point_pre.layer[1].layer
@@ -104,7 +101,8 @@ class InferenceEngine:
 
     # ---- parameter extraction -----------------------------------------------------------
     def _block(self, m):
-        bb, mve = self._bb, self._mve
+        from .refapi.networks import backbone as bb
+        from .refapi.networks import multi_view_encoder as mve
         if isinstance(m, bb.DownSample2D):
             wa, ba = _fold(m.conv_branch[0].weight, None, m.conv_branch[1])
             wp, bp = _fold(m.pool_branch[0].weight, None, m.pool_branch[1])
@@ -132,6 +130,11 @@ class InferenceEngine:
     # ---- blocks ---------------------------------------------------------------------------
     def _run_block(self, x, p, out=None):
         if p.kind == "down":
+            if x.stride(1) == 1 and x.shape[1] > 1:       # channels-last input (the scatter target of stage 0)
+                a = F.conv2d(x, p.wa.contiguous(memory_format=torch.channels_last), None, p.stride, 1)
+                q = F.conv2d(x, p.wp.contiguous(memory_format=torch.channels_last))
+                dst = out if out is not None else torch.empty(a.shape, dtype=a.dtype, device=a.device)
+                return ops.downsample_epilogue(a, q, p.bias, p.stride, out=dst)
             a = F.conv2d(x, p.wa, None, p.stride, 1)
             q = F.conv2d(x, p.wp)
             return ops.downsample_epilogue(a, q, p.bias, p.stride, out=out if out is not None else a)
@@ -152,25 +155,37 @@ class InferenceEngine:
             return ops.channel_gate_residual(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.sums_ws, out=dst)
         return ops.bias_act(y2, p.b2, RELU, out=dst, residual=x)
 
+    @staticmethod
+    def _linear_relu(x, wb):
+        """relu(x @ W^T + b) for a folded 1x1 conv (W [Cout, Cin, 1, 1]) on point rows; the bias + ReLU epilogue
+        is fused into the hipBLASLt GEMM where the runtime offers it."""
+        w = wb[0].view(wb[0].shape[0], -1)
+        try:
+            return torch._addmm_activation(wb[1], x, w.t(), use_gelu=False)
+        except (RuntimeError, AttributeError):
+            return torch.relu_(torch.addmm(wb[1], x, w.t()))
+
     def _run_stage(self, x, blocks, out=None):
         for i, p in enumerate(blocks):
             x = self._run_block(x, p, out if i == len(blocks) - 1 else None)
         return x
 
-    def _cross_view(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_out=None):
+    def _cross_view(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None):
         """cat_buf[:, :c] holds the BEV feature; fills cat_buf[:, c:] with the range-view branch scattered back
-        (multi_view_encoder.py:395-405 / :410-420).  Returns the R2P point features [B, c, N]."""
+        (multi_view_encoder.py:395-405 / :410-420).  B2P gather + P2R scatter and R2P gather + P2B scatter are
+        one kernel each (csrc/point_fused.hip); the channels-last scatter targets are transposed into the NCHW
+        maps the convs want.  point_rows (optional [B,N,c] row view) receives the R2P point features."""
         bev = cat_buf[:, :c]
-        b, n = bev_xy.shape[0], bev_xy.shape[1]
-        pts = ops.bilinear_gather(bev, bev_xy, scale)
-        rv = torch.zeros((b, c) + rv_hw, dtype=torch.float32, device=bev.device)
-        ops.voxel_maxpool_fwd(pts, sphere, rv, rv_hw, scale)
+        b = bev.shape[0]
+        dev = bev.device
+        rv_cl = torch.zeros((b,) + rv_hw + (c,), dtype=torch.float32, device=dev)
+        ops.gather_scatter(bev, bev_xy, scale, sphere, scale, out=rv_cl)
+        rv = ops.nhwc_to_nchw(rv_cl, torch.empty((b, c) + rv_hw, dtype=torch.float32, device=dev))
         rv = self._run_stage(rv, rv_blocks)
-        pts = ops.bilinear_gather(rv, sphere, scale, out=point_out)
         back = cat_buf[:, c:]
-        back.zero_()
-        ops.voxel_maxpool_fwd(pts, bev_xy, back, tuple(back.shape[2:]), scale)
-        return pts
+        back_cl = torch.zeros((b,) + tuple(back.shape[2:]) + (c,), dtype=torch.float32, device=dev)
+        ops.gather_scatter(rv, sphere, scale, bev_xy, scale, out=back_cl, pts_out=point_rows)
+        ops.nhwc_to_nchw(back_cl, back)
 
     def _temporal_fusion(self, x2, memory):
         """DeformAttnModule (multi_view_encoder.py:426-439, 245-321): the memory stream queries the current map."""
@@ -210,30 +225,26 @@ class InferenceEngine:
         bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
         sphere = pcds_sphere_coord[:, 0, :, :, 0].contiguous()
 
-        # point_pre (BN -> 1x1 -> BN -> ReLU -> 1x1 -> BN -> ReLU), then the input scatter
-        x = point_feat.reshape(bs * t, cin, n, 1).float()
-        h = F.conv2d(x, self.pp1[0])
-        ops.bias_act(h, self.pp1[1], RELU, out=h)
-        pts = F.conv2d(h, self.pp2[0])
-        ops.bias_act(pts, self.pp2[1], RELU, out=pts)
-        cpt = pts.shape[1]
+        # point_pre + input scatter in one kernel; the BEV grid is channels-last, the t = 0 point features go
+        # straight into the point-wise fusion buffer [pts(t=0) | bev gather | range-view gather] (point rows)
+        cpt = self.pp2[0].shape[0]
         hb, wb = self.bev_hw
-        bev = torch.zeros((bs * t, cpt, hb, wb), dtype=torch.float32, device=dev)
-        ops.voxel_maxpool_fwd(pts, pcds_coord.reshape(bs * t, n, 3)[:, :, :2].contiguous(), bev, (hb, wb), (1.0, 1.0))
-        bev = bev.view(bs, t * cpt, hb, wb)
+        c_dec, c1 = self.conv_2[0].shape[0], self.res1_bev[-1].w2.shape[0]
+        o1, o2 = cpt, cpt + c_dec
+        fuse = torch.empty((bs, n, cpt + c_dec + c1), dtype=torch.float32, device=dev)
+        bev_cl = torch.zeros((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
+        ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
+                             pts_out=fuse[:, :, :o1])
+        bev = bev_cl.permute(0, 3, 1, 2)            # logical NCHW view of the channels-last buffer
 
         c0 = self.header_bev[-1].w2.shape[0]
         x0cat = torch.empty((bs, 2 * c0, hb // 2, wb // 2), dtype=torch.float32, device=dev)
         self._run_stage(bev, self.header_bev, out=x0cat[:, :c0])
         self._cross_view(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
 
-        c1 = self.res1_bev[-1].w2.shape[0]
         x1cat = torch.empty((bs, 2 * c1, hb // 4, wb // 4), dtype=torch.float32, device=dev)
         self._run_stage(x0cat, self.res1_bev, out=x1cat[:, :c1])
-        # point-wise fusion input [pts(t=0) | bev gather | range-view gather] assembled in place, never cat-ed
-        fuse = torch.empty((bs, cpt + self.conv_2[0].shape[0] + c1, n, 1), dtype=torch.float32, device=dev)
-        o1, o2 = cpt, cpt + self.conv_2[0].shape[0]
-        self._cross_view(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_out=fuse[:, o2:, :, 0])
+        self._cross_view(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:])
 
         x2 = self._run_stage(x1cat, self.res2)
         x2 = self._temporal_fusion(x2, memory)
@@ -246,11 +257,10 @@ class InferenceEngine:
         aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
         k = self.aux[2]
 
-        ops.bilinear_gather(bev_feat, bev_xy, self.grid2point_scale, out=fuse[:, o1:o2, :, 0])
-        fuse[:, :o1].copy_(pts.view(bs, t, cpt, n, 1)[:, 0])
-        z = F.conv2d(fuse, self.post1[0])
-        ops.bias_act(z, self.post1[1], RELU, out=z)
-        z = F.conv2d(z, self.post2[0])
-        ops.bias_act(z, self.post2[1], RELU, out=z)
-        pred = F.conv2d(z, self.pred[0], self.pred[1])
+        ops.gather_scatter(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
+        # CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3
+        z = self._linear_relu(fuse.view(bs * n, -1), self.post1)
+        z = self._linear_relu(z, self.post2)
+        pred = torch.addmm(self.pred[1], z, self.pred[0].view(self.pred[0].shape[0], -1).t())
+        pred = pred.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
         return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2

@@ -263,3 +263,76 @@ def upsample_concat(sources, size, out=None):
                                       len(sources), out.data_ptr(), b, size[0], size[1], _stream(out))
     _lib.check(rc, "smos_upsample_concat")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# fused point-side kernels (inference engine)
+# ---------------------------------------------------------------------------------------------
+def _rows(name, t, c):
+    """(batch pitch, row pitch) of a point-row view [B, N, c] whose last dim is contiguous."""
+    if t.dim() != 3 or t.shape[2] != c or t.stride(2) != 1:
+        raise RuntimeError("%s: expected point rows [B, N, %d] with contiguous channels, got %s / %s" % (name, c, tuple(t.shape), t.stride()))
+    return t.stride(0), t.stride(1)
+
+
+def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None):
+    """xyzi [B,T,7,N(,1)], coord [B,T,N,K(,1)], bev [B,H,W,T*64] zero-filled channels-last, pts_out [B,N,64] rows."""
+    _require_cuda("pointnet_scatter", xyzi, coord, w1, b1, w2, b2, bev, pts_out)
+    b, t, cin, n = xyzi.shape[:4]
+    k = coord.shape[3]
+    if not (xyzi.is_contiguous() and coord.is_contiguous() and bev.is_contiguous()):
+        raise RuntimeError("pointnet_scatter: xyzi, coord and bev must be contiguous")
+    h, w = bev.shape[1], bev.shape[2]
+    cout = w2.shape[0]
+    if bev.shape[3] != t * cout:
+        raise RuntimeError("pointnet_scatter: bev has %d channels, expected %d" % (bev.shape[3], t * cout))
+    po_b = po_n = 0
+    if pts_out is not None:
+        po_b, po_n = _rows("pointnet_scatter", pts_out, cout)
+    lib = _lib.load()
+    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, h, w)):
+        rc = lib.smos_pointnet_scatter(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                       b2.data_ptr(), bev.data_ptr(), pts_out.data_ptr() if pts_out is not None else None,
+                                       po_b, po_n, b, t, n, h, w, cin, w1.shape[0], cout, _stream(xyzi))
+    _lib.check(rc, "smos_pointnet_scatter")
+    return bev
+
+
+def gather_scatter(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None):
+    """grid [B,C,Hg,Wg] any strides; gcoord / scoord [B,N,K] contiguous; out [B,Ho,Wo,C] zero-filled
+    channels-last (or None); pts_out [B,N,C] rows (or None)."""
+    _require_cuda("gather_scatter", grid, gcoord, scoord, out, pts_out)
+    b, c, hg, wg = grid.shape
+    n, kg = gcoord.shape[1], gcoord.shape[2]
+    ho = wo = ks = 0
+    if out is not None:
+        if not out.is_contiguous() or out.shape[3] != c:
+            raise RuntimeError("gather_scatter: out must be contiguous channels-last [B,Ho,Wo,C]")
+        ho, wo, ks = out.shape[1], out.shape[2], scoord.shape[2]
+    po_b = po_n = 0
+    if pts_out is not None:
+        po_b, po_n = _rows("gather_scatter", pts_out, c)
+    lib = _lib.load()
+    label = "gather_scatter[%dx%dx%dx%d->%d->%dx%d]" % (b, c, hg, wg, n, ho, wo)
+    with torch.cuda.device(grid.device), profiling.span(label):
+        rc = lib.smos_gather_scatter(grid.data_ptr(), _lib.i64_array(grid.stride()), gcoord.data_ptr(), kg,
+                                     _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
+                                     _lib.f32_array(sscale) if out is not None else None,
+                                     out.data_ptr() if out is not None else None,
+                                     pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, c, hg, wg, n, ho, wo,
+                                     _stream(grid))
+    _lib.check(rc, "smos_gather_scatter")
+
+
+def nhwc_to_nchw(src, dst):
+    """src [B,H,W,C] contiguous -> dst [B,C,H,W] view with contiguous planes (e.g. a channel slice)."""
+    _require_cuda("nhwc_to_nchw", src, dst)
+    b, h, w, c = src.shape
+    db, dc, hw = _planes("nhwc_to_nchw", dst)
+    if not src.is_contiguous() or tuple(dst.shape) != (b, c, h, w):
+        raise RuntimeError("nhwc_to_nchw: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        rc = lib.smos_nhwc_to_nchw(src.data_ptr(), dst.data_ptr(), db, dc, b, c, hw, _stream(src))
+    _lib.check(rc, "smos_nhwc_to_nchw")
+    return dst

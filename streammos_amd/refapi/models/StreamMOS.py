@@ -58,6 +58,11 @@ class AttNet(nn.Module):
     def invalidate_engine(self):
         self._engine = None
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None             # never pickled / deep-copied: it is a cache
+        return state
+
     def _apply(self, fn, *args, **kwargs):
         self._engine = None
         return super()._apply(fn, *args, **kwargs)

@@ -231,3 +231,77 @@ def test_tta_argmax_matches_torch():
     assert (prob - want).abs().max().item() <= 1e-6
     agree = (labels.long() == want.argmax(1)).float().mean().item()
     assert agree == 1.0 or ((prob.sort(1)[0][:, -1] - prob.sort(1)[0][:, -2])[labels.long() != want.argmax(1)].max() < 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# fused point-side kernels of the inference engine
+# ------------------------------------------------------------------------------------------
+def _model_like_coords(gen, b, n, hi_y, hi_x, pad=0.1):
+    c = torch.stack((torch.rand((b, n), generator=gen) * (hi_y * 1.1) - 0.05 * hi_y,
+                     torch.rand((b, n), generator=gen) * (hi_x * 1.1) - 0.05 * hi_x), -1)
+    c[:, -int(n * pad):] = -4864.0
+    return c
+
+
+@pytest.mark.parametrize("n", [1000, 4096 + 37])
+def test_pointnet_scatter_against_unfused_ops(n):
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    b, t, h, w = 2, 3, 64, 48
+    xyzi = torch.randn((b, t, 7, n, 1), generator=gen).to(DEV)
+    coord = torch.cat((_model_like_coords(gen, b * t, n, h, w), torch.rand((b * t, n, 1), generator=gen)), -1)
+    coord = coord.view(b, t, n, 3, 1).to(DEV)
+    w1, b1 = (torch.randn((64, 7, 1, 1), generator=gen) * 0.4).to(DEV), torch.randn(64, generator=gen).to(DEV) * 0.1
+    w2, b2 = (torch.randn((64, 64, 1, 1), generator=gen) * 0.15).to(DEV), torch.randn(64, generator=gen).to(DEV) * 0.1
+    bev = torch.zeros((b, h, w, t * 64), device=DEV)
+    rows = torch.full((b, n, 192), -7.0, device=DEV)
+    ops.pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=rows[:, :, 64:128])
+    x = xyzi.view(b * t, 7, n, 1).double()
+    pts = F.relu(F.conv2d(F.relu(F.conv2d(x, w1.double(), b1.double())), w2.double(), b2.double())).float()
+    want = torch.zeros((b * t, 64, h, w), device=DEV)
+    ops.voxel_maxpool_fwd(pts, coord.view(b * t, n, 3)[:, :, :2].contiguous(), want, (h, w), (1.0, 1.0))
+    got = bev.permute(0, 3, 1, 2).reshape(b, t, 64, h, w).reshape(b * t, 64, h, w)
+    # same max-scatter, features from an fp32 fma chain vs an fp64 reference: 1e-5 relative
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert ((got > 0) == (want > 0)).float().mean().item() > 0.9999
+    pts0 = pts.view(b, t, 64, n)[:, 0].permute(0, 2, 1)
+    assert (rows[:, :, 64:128] - pts0).abs().max().item() <= 1e-5 * pts0.abs().max().item()
+    assert (rows[:, :, :64] == -7.0).all() and (rows[:, :, 128:] == -7.0).all()
+
+
+@pytest.mark.parametrize("c,hw_g,hw_o,sg,ss", [(32, (64, 64), (8, 256), (0.5, 0.5), (0.5, 0.5)),
+                                              (64, (16, 128), (32, 32), (0.25, 0.25), (0.25, 0.25))])
+def test_gather_scatter_against_unfused_ops(c, hw_g, hw_o, sg, ss):
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    b, n = 2, 5000 + 13
+    grid = torch.relu(torch.randn((b, 2 * c) + hw_g, generator=gen)).to(DEV)[:, c:]          # a channel slice (strided)
+    gcoord = _model_like_coords(gen, b, n, hw_g[0] / sg[0], hw_g[1] / sg[1]).to(DEV)
+    scoord = _model_like_coords(gen, b, n, hw_o[0] / ss[0], hw_o[1] / ss[1]).to(DEV)
+    out = torch.zeros((b,) + hw_o + (c,), device=DEV)
+    rows = torch.zeros((b, n, c + 8), device=DEV)
+    ops.gather_scatter(grid, gcoord, sg, scoord, ss, out=out, pts_out=rows[:, :, 8:])
+    pts = ops.bilinear_gather(grid, gcoord, sg)
+    want = torch.zeros((b, c) + hw_o, device=DEV)
+    ops.voxel_maxpool_fwd(pts, scoord, want, hw_o, ss)
+    assert torch.equal(rows[:, :, 8:], pts.permute(0, 2, 1))
+    assert torch.equal(out.permute(0, 3, 1, 2), want)
+    nchw = torch.full((b, c + 5) + hw_o, 3.0, device=DEV)
+    ops.nhwc_to_nchw(out, nchw[:, 5:])
+    assert torch.equal(nchw[:, 5:], want) and (nchw[:, :5] == 3.0).all()
+    rows2 = torch.zeros((b, n, c), device=DEV)
+    ops.gather_scatter(grid, gcoord, sg, pts_out=rows2)                                       # gather only
+    assert torch.equal(rows2, pts.permute(0, 2, 1))
+
+
+def test_downsample_epilogue_channels_last_kernel():
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(29)
+    for stride, hw in ((2, (64, 200)), (1, (16, 70))):
+        p = torch.randn((2, 64) + hw, generator=gen).to(DEV)
+        a = torch.randn((2, 64, (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1), generator=gen).to(DEV)
+        bias = torch.randn(64, generator=gen).to(DEV)
+        want = torch.relu(a + bias[None, :, None, None] + F.max_pool2d(p, 3, stride, 1))
+        big = torch.zeros((2, 80) + tuple(a.shape[2:]), device=DEV)
+        ops.downsample_epilogue(a.contiguous(memory_format=torch.channels_last), p.contiguous(memory_format=torch.channels_last),
+                                bias, stride, out=big[:, 16:])
+        assert (big[:, 16:] - want).abs().max().item() < 1e-6 and big[:, :16].abs().max().item() == 0
