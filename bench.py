@@ -38,6 +38,19 @@ def algorithmic_bytes(label):
         cells = int(np.prod([int(v) for v in dst.split("x")]))
         d = len(dst.split("x"))
         return 4 * (bs * c * n + bs * n * d + bs * c * cells)
+    if name == "pointnet_scatter":
+        # fused point_pre + input scatter (zero fill of the grid included in the timed span): reads the 7-channel
+        # point features and the 2 used coordinate columns, materialises the [B,512,512,T*64] grid and the t=0
+        # point features; the 491 MB intermediate of the unfused form is not counted because it is never moved
+        src, dst = dims.split("->")
+        b, t, n = (int(v) for v in src.split("x"))
+        cells = int(np.prod([int(v) for v in dst.split("x")]))
+        return 4 * (b * t * 7 * n + b * t * n * 2 + b * cells * t * 64 + b * n * 64)
+    if name == "gather_scatter":
+        src, n, dst = dims.split("->")
+        b, c, h, w = (int(v) for v in src.split("x"))
+        cells = int(np.prod([int(v) for v in dst.split("x")]))
+        return 4 * (b * c * h * w + 4 * b * int(n) + b * c * cells + (b * c * int(n) if cells == 0 else 0))
     if name == "bilinear_gather":
         src, n = dims.split("->")
         b, c, h, w = (int(v) for v in src.split("x"))

@@ -38,20 +38,33 @@ __device__ __forceinline__ int cell_2d(const float* __restrict__ row, float sy, 
   return ok ? (int)py * W + (int)px : -1;
 }
 
-// phase 2: lanes 0-31 take point 2i, lanes 32-63 point 2i+1; lane = channel
+// phase 2: lane = channel; lanes 0-31 walk points 0..31 of the tile, lanes 32-63 points 32..63.
+// LiDAR points arrive ring by ring in azimuth order, so consecutive points very often fall into the same
+// cell (near ground rings put tens of points into one BEV cell): each half keeps a running maximum while
+// the cell does not change and issues ONE row atomic per run instead of one per point.
 __device__ __forceinline__ void rows_phase(const float* __restrict__ tile, const int* __restrict__ cells, int lane,
                                            float* __restrict__ grid_base, int64_t cell_pitch, int ch0,
                                            float* __restrict__ pts_base, int64_t po_n, int n_valid) {
-  const int c = lane & 31, half = lane >> 5;
+  const int c = lane & 31, p0 = (lane >> 5) * (kTileP / 2);
+  int cur = -1;
+  float best = 0.0f;
 #pragma unroll 4
   for (int i = 0; i < kTileP / 2; ++i) {
-    const int p = 2 * i + half;
+    const int p = p0 + i;
     const float v = tile[p * kPitch + c];
     if (pts_base && p < n_valid) pts_base[(int64_t)p * po_n + ch0 + c] = v;
+    if (!grid_base) continue;
     const int cell = cells[p];
-    if (grid_base && cell >= 0 && v > 0.0f)
-      atomicMax(reinterpret_cast<int*>(grid_base + (int64_t)cell * cell_pitch + ch0 + c), __float_as_int(v));
+    if (cell != cur) {
+      if (cur >= 0 && best > 0.0f)
+        atomicMax(reinterpret_cast<int*>(grid_base + (int64_t)cur * cell_pitch + ch0 + c), __float_as_int(best));
+      cur = cell;
+      best = 0.0f;
+    }
+    best = fmaxf(best, v);
   }
+  if (grid_base && cur >= 0 && best > 0.0f)
+    atomicMax(reinterpret_cast<int*>(grid_base + (int64_t)cur * cell_pitch + ch0 + c), __float_as_int(best));
 }
 
 // ---------------------------------------------------------------------------------------------

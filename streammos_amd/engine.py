@@ -232,9 +232,9 @@ class InferenceEngine:
         c_dec, c1 = self.conv_2[0].shape[0], self.res1_bev[-1].w2.shape[0]
         o1, o2 = cpt, cpt + c_dec
         fuse = torch.empty((bs, n, cpt + c_dec + c1), dtype=torch.float32, device=dev)
-        bev_cl = torch.zeros((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
+        bev_cl = torch.empty((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
         ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
-                             pts_out=fuse[:, :, :o1])
+                             pts_out=fuse[:, :, :o1], zero_fill=True)
         bev = bev_cl.permute(0, 3, 1, 2)            # logical NCHW view of the channels-last buffer
 
         c0 = self.header_bev[-1].w2.shape[0]

@@ -275,8 +275,9 @@ def _rows(name, t, c):
     return t.stride(0), t.stride(1)
 
 
-def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None):
-    """xyzi [B,T,7,N(,1)], coord [B,T,N,K(,1)], bev [B,H,W,T*64] zero-filled channels-last, pts_out [B,N,64] rows."""
+def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None, zero_fill=False):
+    """xyzi [B,T,7,N(,1)], coord [B,T,N,K(,1)], bev [B,H,W,T*64] zero-filled channels-last (zero_fill=True clears it
+    here, inside the profiled span), pts_out [B,N,64] rows."""
     _require_cuda("pointnet_scatter", xyzi, coord, w1, b1, w2, b2, bev, pts_out)
     b, t, cin, n = xyzi.shape[:4]
     k = coord.shape[3]
@@ -291,6 +292,8 @@ def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None):
         po_b, po_n = _rows("pointnet_scatter", pts_out, cout)
     lib = _lib.load()
     with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, h, w)):
+        if zero_fill:
+            bev.zero_()
         rc = lib.smos_pointnet_scatter(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                        b2.data_ptr(), bev.data_ptr(), pts_out.data_ptr() if pts_out is not None else None,
                                        po_b, po_n, b, t, n, h, w, cin, w1.shape[0], cout, _stream(xyzi))
