@@ -62,6 +62,16 @@ def algorithmic_bytes(label):
     return 0
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of `label` from the committed rocprofv3 --pmc passes (profiles/pmc_summary.py;
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None if not collected."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_launch"]
+        return table[label]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_frames(n_frames, seq_seed, tta=True):
     """Host preprocessing of a synthetic sequence -> list of (sample, raw_scan, pose)."""
     from streammos_amd import preprocess, synth
@@ -190,7 +200,7 @@ def main():
             ab = algorithmic_bytes(dominant)
             achieved = ab / (mean_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
                     "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(mean_ms, 4), "launches": calls}
         line = {
             "metric": "LiDAR scans/sec (StreamMOS streaming inference + voxel voting)",
