@@ -1,0 +1,101 @@
+"""Stream one SemanticKITTI-format sequence through the MI355X path and write the reference's files.
+
+    python -m streammos_amd.run_sequence --seq-dir .../sequences/08 --out-dir results/sequences/08 \
+        [--checkpoint 40-model.pth] [--no-vote] [--device cuda:0]
+
+Writes ``<out>/predictions/NNNNNN.label`` (network output, the files val_StreamMOS.py:121-126 writes) and, with
+voting, ``<out>/refined/NNNNNN.label`` (the files voxel_voting.py:244-249 writes).  If the sequence has
+``labels/``, the static / moving IoU of both is printed (utils/metric.py formula).  Several sequences are
+sharded over ranks with ``streaming.shard_sequences`` when launched under ``torch.distributed.run``.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import kitti, preprocess, streaming, synth
+
+
+def load_model(checkpoint=None, device="cuda:0"):
+    from .refapi.config import StreamMOS as cfg
+    from .refapi.models import StreamMOS
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    if checkpoint:
+        state = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}
+        model.load_state_dict(state, strict=True)
+    else:
+        model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    return model.to(device).eval()
+
+
+def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_point_num=160000, limit=None, seq_num=3):
+    spec = preprocess.VoxelSpec()
+    files = sorted(f for f in os.listdir(os.path.join(seq_dir, "velodyne")) if f.endswith(".bin"))
+    if limit:
+        files = files[:limit]
+    poses = kitti.read_poses(os.path.join(seq_dir, "poses.txt"), kitti.read_calibration(os.path.join(seq_dir, "calib.txt")))
+    has_gt = os.path.isdir(os.path.join(seq_dir, "labels"))
+    runner = streaming.StreamRunner(model, device, vote=vote)
+    m_raw, m_ref = kitti.MovingIoU(), kitti.MovingIoU()
+    cache = {}
+
+    def scan(i):
+        if i not in cache:
+            cache[i] = kitti.read_scan(os.path.join(seq_dir, "velodyne", files[i]))
+            for k in [k for k in cache if k < i - 12]:
+                del cache[k]
+        return cache[i]
+
+    def gt(i):
+        return kitti.read_label(os.path.join(seq_dir, "labels", files[i][:-4] + ".label"))
+
+    def emit_refined(voted):
+        for fid, lab in voted:
+            lab = lab.cpu().numpy()
+            kitti.write_prediction(os.path.join(out_dir, "refined", files[fid][:-4] + ".label"), lut_labels=lab)
+            if has_gt:
+                m_ref.add(gt(fid), np.where(lab == 251, 2, np.where(lab == 9, 1, 0)))
+
+    for i in range(len(files)):
+        idx = [min(j, len(files) - 1) for j in preprocess.window_indices(i, len(files), seq_num)]
+        sample = preprocess.build_sample([scan(j) for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
+        out = runner.step(runner.upload(sample, scan(i)), poses[i])
+        raw = out["raw_labels"].cpu().numpy()
+        kitti.write_prediction(os.path.join(out_dir, "predictions", files[i][:-4] + ".label"), labels_012=raw)
+        if has_gt:
+            m_raw.add(gt(i), raw)
+        emit_refined(out["voted"])
+    if runner.voter is not None:
+        emit_refined(runner.voter.flush())
+    res = {"sequence": os.path.basename(os.path.normpath(seq_dir)), "scans": len(files)}
+    if has_gt:
+        res["network"] = m_raw.result()
+        if vote:
+            res["voted"] = m_ref.result()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seq-dir", nargs="+", required=True)
+    ap.add_argument("--out-dir", required=True)
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--device", default=None)
+    ap.add_argument("--no-vote", action="store_true")
+    ap.add_argument("--limit", type=int, default=None)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = args.device or "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    lengths = {d: len(os.listdir(os.path.join(d, "velodyne"))) for d in args.seq_dir}
+    mine = streaming.shard_sequences(lengths, world)[rank]
+    model = load_model(args.checkpoint, device)
+    for d in mine:
+        out = os.path.join(args.out_dir, os.path.basename(os.path.normpath(d))) if len(args.seq_dir) > 1 else args.out_dir
+        print(json.dumps(run_sequence(model, d, out, device, vote=not args.no_vote, limit=args.limit)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

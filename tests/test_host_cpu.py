@@ -184,3 +184,25 @@ def test_sequence_sharding_world_size_2_gloo(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line == {"total": 921 + 1061 + 3281 + 631 + 1901, "max_elapsed": 2.0, "world": 2}
+
+
+def test_kitti_formats_round_trip(tmp_path):
+    from streammos_amd import kitti
+    poses = [synth.synthetic_pose(k) for k in range(4)]
+    tr = np.eye(4)
+    tr[:3, 3] = [0.1, -0.2, 0.3]
+    kitti.write_poses(tmp_path / "poses.txt", [tr.dot(p).dot(np.linalg.inv(tr)) for p in poses])
+    kitti.write_calibration(tmp_path / "calib.txt", tr)
+    back = kitti.read_poses(tmp_path / "poses.txt", kitti.read_calibration(tmp_path / "calib.txt"))
+    assert np.abs(np.array(back) - np.array(poses)).max() < 1e-12          # inv(Tr) * pose * Tr (datasets/utils.py:52)
+    scan = synth.synthetic_scan(0, 4, 10)
+    scan.tofile(tmp_path / "000000.bin")
+    assert np.array_equal(kitti.read_scan(tmp_path / "000000.bin"), scan)
+    raw = np.array([0, 1, 40, 252, 9 | (7 << 16), 259 | (3 << 16)], dtype=np.uint32)     # instance ids in the high half
+    raw.tofile(tmp_path / "gt.label")
+    assert kitti.read_label(tmp_path / "gt.label").tolist() == [0, 0, 1, 2, 1, 2]
+    kitti.write_prediction(str(tmp_path / "predictions" / "000000.label"), labels_012=np.array([0, 1, 2]))
+    assert np.fromfile(tmp_path / "predictions" / "000000.label", dtype=np.uint32).tolist() == [0, 9, 251]
+    m = kitti.MovingIoU()
+    m.add(np.array([0, 1, 2, 2, 1]), np.array([2, 1, 2, 1, 1]))
+    assert abs(m.result()["moving_iou"] - 0.5) < 1e-9 and abs(m.result()["static_iou"] - 2 / 3) < 1e-9
