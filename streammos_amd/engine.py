@@ -98,6 +98,7 @@ class InferenceEngine:
         self.sums_ws = torch.zeros(4096, dtype=torch.float32, device=self.device)
         self._shapes = None
         self._lsi = None
+        self._hw = None
 
     # ---- parameter extraction -----------------------------------------------------------
     def _block(self, m):
@@ -191,7 +192,8 @@ class InferenceEngine:
         """DeformAttnModule (multi_view_encoder.py:426-439, 245-321): the memory stream queries the current map."""
         b, c, hh, ww = x2.shape
         dev = x2.device
-        if self._shapes is None or self._shapes[0, 0].item() != hh:
+        if self._shapes is None or self._hw != (hh, ww):
+            self._hw = (hh, ww)
             self._shapes = torch.tensor([[hh, ww]], dtype=torch.long, device=dev)
             self._lsi = torch.zeros((1,), dtype=torch.long, device=dev)
             ys = (torch.arange(hh, dtype=torch.float32, device=dev) + 0.5) / hh

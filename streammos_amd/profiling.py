@@ -49,6 +49,6 @@ def kernel_timer(only=None):
 
 
 def span(label):
-    if _active is None:
+    if _active is None or torch.cuda.is_current_stream_capturing():
         return contextlib.nullcontext()
     return _active.span(label)

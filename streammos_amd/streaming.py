@@ -97,11 +97,52 @@ class VoxelVoter:
 class StreamRunner:
     """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
 
-    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False):
+    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False):
+        """graph=True captures the network forward + TTA reduce of a frame into two hipGraphs (first frame: learned
+        memory embedding; later frames: recurrent memory) that are replayed on static buffers -- one launch per scan
+        instead of ~180.  The per-frame voting stays outside the graph (its pose matrices are launch arguments)."""
         self.device = torch.device(device)
         self.model = model.to(self.device).eval()
         self.voter = VoxelVoter(self.device, recip_quantize=recip_quantize) if vote else None
+        self.use_graph = graph
+        self._graphs = None
         self.reset()
+
+    # ---- hipGraph capture -------------------------------------------------------------------
+    def _forward(self, batch, first):
+        pred_cls, _, _, _, mem = self.model.infer(batch, 0 if first else 1, None if first else self._g_mem)
+        return pred_cls, ops.tta_argmax(pred_cls), mem
+
+    def _capture(self, dev):
+        keys = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
+        self._g_in = {k: torch.empty_like(dev[k]) for k in keys}
+        for k in keys:
+            self._g_in[k].copy_(dev[k])
+        batch = {k: self._g_in[k].unsqueeze(0) for k in keys}
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            # eager warm-up on the capture stream: MIOpen algorithm search, lazy engine build, allocator pools
+            _, _, mem = self._warm(batch)
+            self._g_mem = mem.clone()
+            for _ in range(2):
+                self._forward(batch, False)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graphs = {}
+        for first in (True, False):
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                pred, labels, mem = self._forward(batch, first)
+                self._g_mem.copy_(mem)
+            self._graphs[first] = (g, pred, labels)
+
+    def _warm(self, batch):
+        pred, labels, mem = None, None, None
+        for _ in range(2):
+            pred_cls, _, _, _, mem = self.model.infer(batch, 0, None)
+            labels = ops.tta_argmax(pred_cls)
+        return pred, labels, mem
 
     def reset(self):
         self.memory = None
@@ -124,9 +165,18 @@ class StreamRunner:
     def step(self, dev, pose=None):
         """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
         voted = [(frame_id, int32 LUT labels)])."""
-        batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
-        pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
-        labels = ops.tta_argmax(pred_cls)
+        if self.use_graph:
+            if self._graphs is None or any(self._g_in[k].shape != dev[k].shape for k in self._g_in):
+                self._capture(dev)
+            for k, buf in self._g_in.items():
+                buf.copy_(dev[k])
+            g, pred_cls, labels = self._graphs[self.frame == 0]
+            g.replay()
+            self.memory = self._g_mem       # static buffers: valid until the next step()
+        else:
+            batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+            pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
+            labels = ops.tta_argmax(pred_cls)
         out = {"pred_cls": pred_cls, "labels": labels, "voted": []}
         if "valid_index" in dev:
             raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)

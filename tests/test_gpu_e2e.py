@@ -230,3 +230,23 @@ def test_run_sequence_writes_reference_file_formats(tmp_path):
         for sub in ("predictions", "refined"):
             words = np.fromfile(out / sub / ("%06d.label" % k), dtype=np.uint32)
             assert words.shape[0] == npts and set(np.unique(words)) <= {0, 9, 251}
+
+
+def test_graph_replay_equals_eager(model):
+    """StreamRunner(graph=True) replays captured hipGraphs; labels and logits must equal the eager engine's."""
+    spec = preprocess.VoxelSpec()
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(6)]
+    poses = [synth.synthetic_pose(k) for k in range(6)]
+    res = {}
+    for graph in (False, True):
+        runner = streaming.StreamRunner(model, DEV, vote=False, graph=graph)
+        outs = []
+        for i in range(4):
+            idx = preprocess.window_indices(i, 6, 3)
+            sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+            o = runner.step(runner.upload(sample, scans[i]), poses[i])
+            outs.append((o["pred_cls"].clone(), o["labels"].clone(), o["raw_labels"].clone()))
+        res[graph] = outs
+    for (p0, l0, r0), (p1, l1, r1) in zip(res[False], res[True]):
+        assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
+        assert (l0 == l1).float().mean().item() >= 0.9995 and (r0 == r1).float().mean().item() >= 0.9995
