@@ -189,6 +189,28 @@ int smos_gather_scatter(const float* grid, const int64_t* grid_stride, const flo
 int smos_nhwc_to_nchw(const float* src, float* dst, int64_t ds_b, int64_t ds_c, int64_t B, int64_t C, int64_t HW,
                       smos_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Device-side validation preprocessing (csrc/preprocess.hip): what DataloadVal does with
+ * numpy per sample (datasets/data_StreamMOS.py:397-599, datasets/utils.py:98-192).
+ *   range6     host doubles {x_lo, x_hi, y_lo, y_hi, z_lo, z_hi}     (config Voxel.range_*)
+ *   bev_size3  host int64   {512, 512, 30}                            (config Voxel.bev_shape)
+ *   rv4        host doubles {phi_hi, dphi, theta_hi, dtheta} in radians (datasets/utils.py:176-181)
+ */
+/* moved[i] = (float32)(pose_diff * (x, y, z, 1)) computed in float64, intensity carried; mask[i] = lo <= p < hi.
+ * pose_diff: host, 16 doubles row-major, or NULL (identity, the current scan). */
+int smos_prep_transform_mask(const float* scan, int64_t n, const double* pose_diff, const double* range6, float* moved,
+                             int32_t* mask, smos_stream_t stream);
+/* Writes scan t of every TTA variant v (x *= tta_sx[v], y *= tta_sy[v]; V <= 4):
+ *   xyzi [V,T,7,N] = (x, y, z, intensity, dist, frac(x_quan), frac(y_quan)), coord [V,T,N,3] = (x,y,z)_quan,
+ *   sphere [V,T,N,2] = (theta_quan, phi_quan); kept points are compacted in order (slot prefix[i]-1, prefix = inclusive
+ * prefix sum of mask), slots >= count hold the reference's padding point (-1000, -1000, -4000, -1000). */
+int smos_prep_emit(const float* moved, const int32_t* mask, const int32_t* prefix, int64_t n, int32_t t, int32_t T, int64_t N,
+                   int32_t V, const float* tta_sx, const float* tta_sy, const double* range6, const int64_t* bev_size3,
+                   const double* rv4, float* xyzi, float* coord, float* sphere, smos_stream_t stream);
+/* raw[i] = mask[i] ? labels[prefix[i]-1] : 0   (val_StreamMOS.py:112-118) */
+int smos_prep_unpad_labels(const uint8_t* labels, int64_t N, const int32_t* mask, const int32_t* prefix, int64_t n,
+                           uint8_t* raw, smos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,9 @@ SIGNATURES = {
     "smos_pointnet_scatter": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
+    "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],
+    "smos_prep_emit": [vp, vp, vp, i64, i32, i32, i64, i32, c_f32p, c_f32p, c_f64p, c_i64p, c_f64p, vp, vp, vp, vp],
+    "smos_prep_unpad_labels": [vp, i64, vp, vp, i64, vp, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }
 

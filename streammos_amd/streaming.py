@@ -162,6 +162,21 @@ class StreamRunner:
         return dev
 
     @torch.no_grad()
+    def step_raw(self, scans, poses, frame_point_num=160000):
+        """One scan from RAW data: scans = list of T host (numpy) or device [n,4] float32 scans, current first;
+        poses = their 4x4 poses.  Preprocessing runs on the device (streammos_amd.device_preprocess, row f1):
+        only the raw scans cross PCIe and nothing synchronises with the host."""
+        from .device_preprocess import DevicePreprocessor
+        if getattr(self, "_pre", None) is None or self._pre.N != frame_point_num:
+            self._pre = DevicePreprocessor(self.device, frame_point_num=frame_point_num)
+        dev_scans = [s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s)) for s in scans]
+        dev_scans = [s.to(self.device, non_blocking=True) for s in dev_scans]
+        inv_cur = np.linalg.inv(np.asarray(poses[0], dtype=np.float64))
+        built = self._pre.build(dev_scans, [None] + [inv_cur.dot(p) for p in poses[1:]])
+        built["raw_scan"] = dev_scans[0]
+        return self.step(built, poses[0])
+
+    @torch.no_grad()
     def step(self, dev, pose=None):
         """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
         voted = [(frame_id, int32 LUT labels)])."""
@@ -178,9 +193,13 @@ class StreamRunner:
             pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
             labels = ops.tta_argmax(pred_cls)
         out = {"pred_cls": pred_cls, "labels": labels, "voted": []}
-        if "valid_index" in dev:
+        raw = None
+        if "prefix" in dev:                                                       # device-preprocessed sample
+            raw = self._pre.unpad_labels(labels, dev)
+        elif "valid_index" in dev:
             raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
             raw.index_copy_(0, dev["valid_index"], labels[:dev["n_valid"]])      # val_StreamMOS.py:112-118
+        if raw is not None:
             out["raw_labels"] = raw
             if self.voter is not None and "raw_scan" in dev:
                 out["voted"] = self.voter.push(dev["raw_scan"], raw, pose if pose is not None else np.eye(4))

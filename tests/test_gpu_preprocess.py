@@ -1,0 +1,73 @@
+"""Device-side preprocessing (row f1) against the host numpy restatement, which is bit-exact against the reference."""
+import numpy as np
+import pytest
+import torch
+
+from streammos_amd import device_preprocess, preprocess, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("beams,azimuth,npad", [(16, 120, 2048), (64, 1875, 160000)])
+def test_device_preprocess_matches_host(beams, azimuth, npad):
+    spec = preprocess.VoxelSpec()
+    scans = [synth.synthetic_scan(k, beams, azimuth) for k in (5, 4, 3)]
+    poses = [synth.synthetic_pose(k) for k in (5, 4, 3)]
+    # push a few points exactly onto the half-open range boundaries
+    scans[0][:4, :3] = [[-50.0, 0, 0], [50.0, 0, 0], [49.999996, 1, -4.0], [0, -50.0, 1.9999999]]
+    host = preprocess.build_sample(scans, poses, npad, spec, tta=True)
+    pre = device_preprocess.DevicePreprocessor(DEV, spec, npad, tta=True)
+    inv_cur = np.linalg.inv(poses[0])
+    built = pre.build([torch.from_numpy(s).to(DEV) for s in scans], [None] + [inv_cur.dot(p) for p in poses[1:]])
+    assert np.array_equal(built["mask"].cpu().numpy().astype(bool), host["valid_mask"])
+    n_valid = int(host["valid_mask"].sum())
+    assert int(built["prefix"][-1]) == n_valid == npad - host["pad_length"]
+    xyzi, coord, sph = (built[k].cpu().numpy() for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"))
+    assert xyzi.shape == host["pcds_xyzi"].shape and coord.shape == host["pcds_coord"].shape
+    # current scan (t = 0, no pose transform): everything except the range-view angles is bit-exact
+    assert np.array_equal(coord[:, 0], host["pcds_coord"][:, 0])
+    assert np.array_equal(xyzi[:, 0], host["pcds_xyzi"][:, 0])
+    # history scans went through the float64 pose product: float32 results equal up to 1 ulp on a handful of points
+    d = np.abs(coord - host["pcds_coord"])
+    assert (d == 0).mean() > 0.9999 and d.max() <= 2e-4
+    d = np.abs(xyzi - host["pcds_xyzi"])
+    assert (d == 0).mean() > 0.9999 and d.max() <= 1e-3
+    # asinf / atan2f vs numpy's SIMD routines: a few ulp on the angle, i.e. <= 1e-3 of a range-image cell,
+    # and the same range-image cell (after the model's 0.5 scale) for all but a vanishing fraction of points
+    ds = np.abs(sph - host["pcds_sphere_coord"])
+    assert ds.max() <= 2e-3
+    same_cell = np.floor(sph * 0.5) == np.floor(host["pcds_sphere_coord"] * 0.5)
+    assert same_cell.mean() >= 0.9999
+    # labels back to the raw scan
+    lab = torch.randint(0, 3, (npad,), dtype=torch.uint8, device=DEV)
+    raw = pre.unpad_labels(lab, built).cpu().numpy()
+    want = np.zeros(scans[0].shape[0], dtype=np.uint8)
+    want[host["valid_mask"]] = lab.cpu().numpy()[:n_valid]
+    assert np.array_equal(raw, want)
+
+
+def test_step_raw_equals_host_preprocessed_step():
+    """StreamRunner.step_raw (device preprocessing) against step() on host-preprocessed inputs: same labels for the
+    raw scan except where a 1-ulp angle difference moves a point across a range-image cell (< 0.1 %)."""
+    from streammos_amd import streaming
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    spec = preprocess.VoxelSpec()
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(6)]
+    poses = [synth.synthetic_pose(k) for k in range(6)]
+    a = streaming.StreamRunner(model, DEV, vote=True)
+    b = streaming.StreamRunner(model, DEV, vote=True)
+    a.voter.window = b.voter.window = 3
+    for i in range(4):
+        idx = preprocess.window_indices(i, 6, 3)
+        sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+        oa = a.step(a.upload(sample, scans[i]), poses[i])
+        ob = b.step_raw([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048)
+        assert (oa["pred_cls"] - ob["pred_cls"]).abs().max().item() <= 2e-3 * oa["pred_cls"].abs().max().item()
+        assert (oa["raw_labels"] == ob["raw_labels"]).float().mean().item() >= 0.999
+        assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
+        for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
+            assert (la == lb).float().mean().item() >= 0.999
