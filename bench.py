@@ -218,6 +218,24 @@ def main():
                               "note": "scans/s/GPU x 11.2 GB algorithmic bytes per scan (SURVEY.md 8d)"},
             "hip_kernel_ms_per_step": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
+        if world == 1:
+            # PCIe-inclusive variant (never `value`): raw scans uploaded every step, preprocessing on the device
+            raw_runner = streaming.StreamRunner(model, device, vote=not args.no_vote)
+            from streammos_amd import synth as _synth
+            raw = [(_synth.synthetic_scan(k), _synth.synthetic_pose(k)) for k in range(6)]
+            def raw_step(i):
+                idx = [(i + 2) % 4 + 2 - j for j in range(3)]
+                raw_runner.step_raw([raw[j][0] for j in idx], [raw[j][1] for j in idx], FRAME_POINT_NUM)
+            for i in range(3):
+                raw_step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(20):
+                raw_step(i)
+            torch.cuda.synchronize()
+            line["raw_scan_pipeline"] = {"value": round(20 / (time.perf_counter() - t1), 3), "unit": "scans/s",
+                                         "note": "H2D of 3 raw scans (5.8 MB) + device preprocessing + the same step; "
+                                                 "PCIe-inclusive, reported beside `value`, never as `value`"}
         if world == 1 and args.cpu_scans > 0:
             line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
         print(json.dumps(line), flush=True)

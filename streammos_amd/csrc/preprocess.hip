@@ -63,7 +63,9 @@ __device__ __forceinline__ void emit_point(const EmitArgs& a, int64_t j, float x
     const float qy = __fdiv_rn(__fsub_rn(y, a.g.lo[1]), a.g.cell[1]);
     const float qz = __fdiv_rn(__fsub_rn(z, a.g.lo[2]), a.g.cell[2]);
     // d = sqrt(x^2 + y^2 + z^2) + 1e-12 in float32, summed left to right
-    const float d = __fadd_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z))), 1e-12f);
+    // the float32 square root is taken in float64 and rounded once: correctly rounded like numpy's (v_sqrt_f32 is not)
+    const float ss = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    const float d = __fadd_rn((float)sqrt((double)ss), 1e-12f);
     const float phi_q = __fdiv_rn(__fsub_rn(a.g.phi_hi, atan2f(x, y)), a.g.dphi);
     const float th_q = __fdiv_rn(__fsub_rn(a.g.th_hi, asinf(__fdiv_rn(z, d))), a.g.dtheta);
     const int64_t s = (int64_t)v * a.T + a.t;

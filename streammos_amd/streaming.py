@@ -172,7 +172,9 @@ class StreamRunner:
         dev_scans = [s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s)) for s in scans]
         dev_scans = [s.to(self.device, non_blocking=True) for s in dev_scans]
         inv_cur = np.linalg.inv(np.asarray(poses[0], dtype=np.float64))
-        built = self._pre.build(dev_scans, [None] + [inv_cur.dot(p) for p in poses[1:]])
+        # the current scan also goes through inv(P_cur) * P_cur, which is the identity only up to rounding
+        # (the reference does exactly that, datasets/data_StreamMOS.py:424-467)
+        built = self._pre.build(dev_scans, [inv_cur.dot(np.asarray(p, dtype=np.float64)) for p in poses])
         built["raw_scan"] = dev_scans[0]
         return self.step(built, poses[0])
 

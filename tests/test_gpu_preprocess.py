@@ -19,20 +19,19 @@ def test_device_preprocess_matches_host(beams, azimuth, npad):
     host = preprocess.build_sample(scans, poses, npad, spec, tta=True)
     pre = device_preprocess.DevicePreprocessor(DEV, spec, npad, tta=True)
     inv_cur = np.linalg.inv(poses[0])
-    built = pre.build([torch.from_numpy(s).to(DEV) for s in scans], [None] + [inv_cur.dot(p) for p in poses[1:]])
+    built = pre.build([torch.from_numpy(s).to(DEV) for s in scans], [inv_cur.dot(p) for p in poses])
     assert np.array_equal(built["mask"].cpu().numpy().astype(bool), host["valid_mask"])
     n_valid = int(host["valid_mask"].sum())
     assert int(built["prefix"][-1]) == n_valid == npad - host["pad_length"]
     xyzi, coord, sph = (built[k].cpu().numpy() for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"))
     assert xyzi.shape == host["pcds_xyzi"].shape and coord.shape == host["pcds_coord"].shape
-    # current scan (t = 0, no pose transform): everything except the range-view angles is bit-exact
-    assert np.array_equal(coord[:, 0], host["pcds_coord"][:, 0])
-    assert np.array_equal(xyzi[:, 0], host["pcds_xyzi"][:, 0])
-    # history scans went through the float64 pose product: float32 results equal up to 1 ulp on a handful of points
+    # the float64 pose product is summed in a fixed order here and in BLAS order on the host: the float32
+    # results are equal except for 1-ulp differences on a handful of points
     d = np.abs(coord - host["pcds_coord"])
     assert (d == 0).mean() > 0.9999 and d.max() <= 2e-4
     d = np.abs(xyzi - host["pcds_xyzi"])
-    assert (d == 0).mean() > 0.9999 and d.max() <= 1e-3
+    report = [(c, float((d[:, :, c] == 0).mean()), float(d[:, :, c].max())) for c in range(7)]
+    assert (d == 0).mean() > 0.9999 and d.max() <= 1e-3, report
     # asinf / atan2f vs numpy's SIMD routines: a few ulp on the angle, i.e. <= 1e-3 of a range-image cell,
     # and the same range-image cell (after the model's 0.5 scale) for all but a vanishing fraction of points
     ds = np.abs(sph - host["pcds_sphere_coord"])
