@@ -211,6 +211,16 @@ int smos_prep_emit(const float* moved, const int32_t* mask, const int32_t* prefi
 int smos_prep_unpad_labels(const uint8_t* labels, int64_t N, const int32_t* mask, const int32_t* prefix, int64_t n,
                            uint8_t* raw, smos_stream_t stream);
 
+/* Multi-scale deformable attention, backward (training row f2).  Replaces
+ * MultiScaleDeformableAttention.ms_deform_attn_backward (deformattn/src/cuda/ms_deform_attn_cuda.cu:83-153, kernels
+ * ms_deform_im2col_cuda.cuh:87-159,301-920).  grad_out [N,Lq,M*D]; grad_value [N,S,M,D] MUST be zero-filled by the
+ * caller (accumulated with atomic adds); grad_sampling_loc [N,Lq,M,L,P,2] and grad_attn_weight [N,Lq,M,L,P] are
+ * fully written. */
+int smos_msda_bwd(const void* grad_out, const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                  const void* sampling_loc, const void* attn_weight, void* grad_value, void* grad_sampling_loc,
+                  void* grad_attn_weight, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                  int32_t dtype, smos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ SIGNATURES = {
     "smos_voxel_maxpool_bwd": [vp, c_i64p, vp, vp, vp, c_i64p, vp, i64, i64, i64, i32, c_i64p, c_f32p, i32, vp],
     "smos_bilinear_gather_fwd": [vp, c_i64p, vp, i32, vp, c_i64p, i64, i64, i64, i64, i64, c_f32p, vp],
     "smos_msda_fwd": [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp],
+    "smos_msda_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp],
     "smos_tta_argmax": [vp, i64, i64, i64, vp, vp, vp],
     "smos_vote_clear": [vp, vp],
     "smos_vote_accumulate": [vp, i64, i64, vp, c_f64p, i32, vp, vp],

@@ -121,6 +121,87 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_d32(const float* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward (training row f2): replaces the col2im kernel family of the reference
+// (ms_deform_im2col_cuda.cuh:87-159 bilinear part, :301-920 the per-channel-count reduction variants).
+// One lane group (32 or 64 lanes) per (batch, query, head); lanes stride over the D channels, accumulate their
+// partial d/d(loc) and d/d(attn) per sample in registers and combine them with wave shuffles -- no shared
+// memory, no block-serial reduction; grad_value is accumulated with native float / double atomic adds.
+template <typename T, int kGroup>
+__global__ __launch_bounds__(kBlock) void msda_bwd(const T* __restrict__ grad_out, const T* __restrict__ value,
+                                                   const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                                                   const T* __restrict__ loc, const T* __restrict__ attn,
+                                                   T* __restrict__ grad_value, T* __restrict__ grad_loc,
+                                                   T* __restrict__ grad_attn, int64_t n_heads_total, int S, int M, int D,
+                                                   int L, int Lq, int P) {
+  constexpr int kGroups = kBlock / kGroup;
+  const int lane = threadIdx.x % kGroup;
+  const int64_t wstride = (int64_t)M * D;
+  for (int64_t hq = (int64_t)blockIdx.x * kGroups + threadIdx.x / kGroup; hq < n_heads_total;
+       hq += (int64_t)gridDim.x * kGroups) {
+    const int m = (int)(hq % M);
+    const int64_t b = hq / ((int64_t)M * Lq);
+    int64_t wptr = hq * L * P;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int64_t base = (b * S + lsi[l]) * wstride + (int64_t)m * D;
+      for (int p = 0; p < P; ++p, ++wptr) {
+        const T loc_w = loc[2 * wptr], loc_h = loc[2 * wptr + 1], aw = attn[wptr];
+        const T h_im = loc_h * H - (T)0.5, w_im = loc_w * W - (T)0.5;
+        T g_w = 0, g_h = 0, g_a = 0;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const T lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          const bool t = h_low >= 0, bt = h_high <= H - 1, lf = w_low >= 0, rt = w_high <= W - 1;
+          const int64_t o1 = base + ((int64_t)h_low * W + w_low) * wstride, o2 = o1 + wstride;
+          const int64_t o3 = o1 + (int64_t)W * wstride, o4 = o3 + wstride;
+          for (int c = lane; c < D; c += kGroup) {
+            const T top = grad_out[hq * D + c];
+            const T tgv = top * aw;
+            T gh = 0, gw = 0, val = 0;
+            if (t && lf) {
+              const T v = value[o1 + c];
+              gh -= hw * v; gw -= hh * v; val += hh * hw * v;
+              atomicAdd(grad_value + o1 + c, hh * hw * tgv);
+            }
+            if (t && rt) {
+              const T v = value[o2 + c];
+              gh -= lw * v; gw += hh * v; val += hh * lw * v;
+              atomicAdd(grad_value + o2 + c, hh * lw * tgv);
+            }
+            if (bt && lf) {
+              const T v = value[o3 + c];
+              gh += hw * v; gw -= lh * v; val += lh * hw * v;
+              atomicAdd(grad_value + o3 + c, lh * hw * tgv);
+            }
+            if (bt && rt) {
+              const T v = value[o4 + c];
+              gh += lw * v; gw += lh * v; val += lh * lw * v;
+              atomicAdd(grad_value + o4 + c, lh * lw * tgv);
+            }
+            g_a += top * val;
+            g_w += (T)W * gw * tgv;
+            g_h += (T)H * gh * tgv;
+          }
+        }
+#pragma unroll
+        for (int off = kGroup / 2; off > 0; off >>= 1) {
+          g_w += __shfl_down(g_w, off, kGroup);
+          g_h += __shfl_down(g_h, off, kGroup);
+          g_a += __shfl_down(g_a, off, kGroup);
+        }
+        if (lane == 0) {
+          grad_loc[2 * wptr] = g_w;
+          grad_loc[2 * wptr + 1] = g_h;
+          grad_attn[wptr] = g_a;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace smos
 
 using namespace smos;
@@ -157,4 +238,32 @@ extern "C" int smos_msda_fwd(const void* value, const int64_t* spatial_shapes, c
                        (const double*)attn_weight, (double*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
   }
   return check_launch("msda_fwd");
+}
+
+extern "C" int smos_msda_bwd(const void* grad_out, const void* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const void* sampling_loc, const void* attn_weight,
+                             void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int64_t N, int64_t S, int64_t M,
+                             int64_t D, int64_t L, int64_t Lq, int64_t P, int32_t dtype, smos_stream_t stream) {
+  SMOS_REQUIRE(N >= 0 && S >= 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_bwd: bad sizes");
+  if (dtype != SMOS_F32 && dtype != SMOS_F64) {
+    set_error("msda_bwd: dtype code %d not implemented (float/double only, like the reference)", (int)dtype);
+    return SMOS_ERR_UNSUPPORTED;
+  }
+  const int64_t heads = N * Lq * M;
+  if (heads == 0) return SMOS_OK;
+  SMOS_REQUIRE(grad_out && value && spatial_shapes && level_start_index && sampling_loc && attn_weight && grad_value &&
+                   grad_sampling_loc && grad_attn_weight, "msda_bwd: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+#define SMOS_BWD(T, G)                                                                                                  \
+  hipLaunchKernelGGL((msda_bwd<T, G>), dim3(grid_for(heads * G, kBlock, 256 * 16)), dim3(kBlock), 0, s, (const T*)grad_out,   \
+                     (const T*)value, spatial_shapes, level_start_index, (const T*)sampling_loc, (const T*)attn_weight,  \
+                     (T*)grad_value, (T*)grad_sampling_loc, (T*)grad_attn_weight, heads, (int)S, (int)M, (int)D, (int)L,  \
+                     (int)Lq, (int)P)
+  if (dtype == SMOS_F32) {
+    if (D <= 32) SMOS_BWD(float, 32); else SMOS_BWD(float, 64);
+  } else {
+    if (D <= 32) SMOS_BWD(double, 32); else SMOS_BWD(double, 64);
+  }
+#undef SMOS_BWD
+  return check_launch("msda_bwd");
 }

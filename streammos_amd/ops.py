@@ -65,12 +65,16 @@ def voxel_maxpool_fwd(feat, ind, out, out_size, scale, voxel_max_idx=None):
 
 def voxel_maxpool_bwd(feat, ind, out, grad_out, grad_feat, out_size, scale):
     _require_cuda("voxel_maxpool_bwd", feat, ind, out, grad_out, grad_feat)
-    if grad_out.stride() != out.stride():
+    # grad_out is read with out's strides and grad_feat written with feat's: same logical layout required
+    # (strides of size-1 dims are arbitrary, so compare through contiguity / explicit equality on real dims)
+    def _same_layout(a, b):
+        return all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+    if not _same_layout(grad_out, out):
         grad_out = grad_out.contiguous()
-        if grad_out.stride() != out.stride():
-            raise RuntimeError("voxel_maxpool_bwd: grad_out strides must match out")
-    if grad_feat.stride() != feat.stride():
-        raise RuntimeError("voxel_maxpool_bwd: grad_feat strides must match feat")
+        if not _same_layout(grad_out, out):
+            raise RuntimeError("voxel_maxpool_bwd: grad_out layout must match out")
+    if not _same_layout(grad_feat, feat):
+        raise RuntimeError("voxel_maxpool_bwd: grad_feat layout must match feat")
     bs, c, n = feat.shape[0], feat.shape[1], feat.shape[2]
     lib = _lib.load()
     with torch.cuda.device(feat.device):
@@ -126,6 +130,27 @@ def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
                                _dtype_code("ms_deform_attn_forward", value), _stream(value))
     _lib.check(rc, "smos_msda_fwd")
     return out
+
+
+def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
+    """Returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    _require_cuda("ms_deform_attn_backward", value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
+    for name, t in (("value", value), ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    n, s, m, d = value.shape
+    lq, l, p = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    g_value = torch.zeros_like(value)
+    g_loc = torch.empty_like(sampling_loc)
+    g_attn = torch.empty_like(attn_weight)
+    lib = _lib.load()
+    with torch.cuda.device(value.device), profiling.span("msda_bwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+        rc = lib.smos_msda_bwd(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                               sampling_loc.data_ptr(), attn_weight.data_ptr(), g_value.data_ptr(), g_loc.data_ptr(),
+                               g_attn.data_ptr(), n, s, m, d, l, lq, p, _dtype_code("ms_deform_attn_backward", value),
+                               _stream(value))
+    _lib.check(rc, "smos_msda_bwd")
+    return g_value, g_loc, g_attn
 
 
 def tta_argmax(pred, want_prob=False):

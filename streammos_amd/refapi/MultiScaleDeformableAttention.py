@@ -19,5 +19,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
-    raise RuntimeError("ms_deform_attn_backward: the backward sampler (training row f2 of SURVEY.md section 8) "
-                       "is not part of this build yet; the inference path never calls it")
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]  (deformattn/src/cuda/ms_deform_attn_cuda.cu:83-153)"""
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    return list(ops.msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output.contiguous()))

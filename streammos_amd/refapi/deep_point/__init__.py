@@ -32,6 +32,7 @@ class VoxelMaxPoolFunction(Function):
         output_size = tuple(int(s) for s in output_size)
         scale_rate = tuple(float(s) for s in scale_rate)
         pcds_ind = pcds_ind.contiguous()
+        pcds_feat = pcds_feat.contiguous()
         voxel_out = pcds_feat.new_zeros((pcds_feat.size(0), pcds_feat.size(1)) + output_size)
         if pcds_feat.is_cuda:
             ops.voxel_maxpool_fwd(pcds_feat, pcds_ind, voxel_out, output_size, scale_rate)
@@ -49,7 +50,7 @@ class VoxelMaxPoolFunction(Function):
         pcds_feat, pcds_ind, voxel_out = ctx.saved_tensors
         output_size, scale_rate = ctx.geometry
         grad_voxel_out = grad_voxel_out.contiguous()
-        grad_feat = torch.zeros_like(pcds_feat)
+        grad_feat = torch.zeros(pcds_feat.shape, dtype=pcds_feat.dtype, device=pcds_feat.device)
         if pcds_feat.is_cuda:
             ops.voxel_maxpool_bwd(pcds_feat, pcds_ind, voxel_out, grad_voxel_out, grad_feat, output_size, scale_rate)
         else:

@@ -117,8 +117,36 @@ class AttNet(nn.Module):
             return self.stage_forward(*args, return_query=True)
         return self.stage_forward(*args, query_embed_store=query_embed_store, use_query_store=True, return_query=True)
 
+    # ---- training (row f2) --------------------------------------------------------------------
+    def _seg_loss(self, pred, target):
+        from . import losses
+        mode = self.pModel.loss_mode
+        if mode == "ohem":
+            ce = losses.ohem_cross_entropy(pred, target, top_ratio=0.2, top_weight=4.0, ignore_index=0)
+        elif mode == "ce":
+            ce = torch.nn.functional.cross_entropy(pred, target.long(), ignore_index=0)
+        else:
+            raise Exception('loss_mode must in ["ce", "ohem"]')      # "wce" needs the dataset yaml, not on this path
+        return ce + 3 * losses.lovasz_softmax(pred, target, ignore=0)
+
+    def single_forward(self, batch, query_embed_store=None, use_query_store=False, return_query=False):
+        """One training step of the chain: point loss + the mean of the three BEV auxiliary losses
+        (models/StreamMOS.py:124-153)."""
+        pred_cls, aux0, aux1, aux2, memory = self.stage_forward(batch["pcds_xyzi"], batch["pcds_coord"],
+                                                                 batch["pcds_sphere_coord"], query_embed_store,
+                                                                 use_query_store, return_query)
+        bs, k = pred_cls.shape[0], pred_cls.shape[1]
+        bev_target = batch["pcds_bev_target"].view(bs, -1, 1)
+        loss = self._seg_loss(pred_cls, batch["pcds_target"])
+        aux = sum(self._seg_loss(a.view(bs, k, -1).unsqueeze(-1), bev_target) for a in (aux0, aux1, aux2))
+        return loss + aux / 3, memory
+
     def forward(self, batch):
-        raise NotImplementedError(
-            "AttNet.forward (three chained training steps with OHEM-CE + Lovasz losses, models/StreamMOS.py:155-179) "
-            "belongs to the training row f2 of SURVEY.md section 8, which this build has not reached; inference "
-            "goes through .infer()/.stage_forward()")
+        """Three consecutive samples chained through the memory (models/StreamMOS.py:155-179); returns the mean loss."""
+        memory, total = None, 0
+        for i in range(3):
+            step = {k: batch["%s_%d" % (k, i)] for k in ("pcds_target", "pcds_bev_target", "pcds_xyzi", "pcds_coord",
+                                                        "pcds_sphere_coord")}
+            loss, memory = self.single_forward(step, query_embed_store=memory, use_query_store=i > 0, return_query=True)
+            total = total + loss
+        return total / 3

@@ -61,8 +61,10 @@ def voxel_maxpooling_cpu_forward(pcds_feat, pcds_ind, voxel_out, voxel_max_idx, 
 def voxel_maxpooling_cpu_backward(pcds_feat, pcds_ind, voxel_out, voxel_max_idx, grad_pcds_feat, grad_voxel_out,
                                   voxel_out_size, voxel_out_stride, output_size, scale_rate):
     code, d, fs, os_, size, scale = _common(pcds_feat, pcds_ind, voxel_out, scale_rate)
-    if grad_voxel_out.stride() != voxel_out.stride() or grad_pcds_feat.stride() != pcds_feat.stride():
-        raise RuntimeError("point_deep.cpu_kernel: gradient strides must match their tensors")
+    # strides of size-1 dims are arbitrary, so layouts are compared through contiguity, not stride tuples
+    if not (grad_voxel_out.is_contiguous() and voxel_out.is_contiguous() and grad_pcds_feat.is_contiguous()
+            and pcds_feat.is_contiguous()):
+        raise RuntimeError("point_deep.cpu_kernel: backward expects contiguous tensors")
     rc = _load().smos_cpu_voxel_maxpool_bwd(pcds_feat.data_ptr(), fs, pcds_ind.data_ptr(), voxel_out.data_ptr(),
                                             grad_voxel_out.data_ptr(), os_, grad_pcds_feat.data_ptr(), pcds_feat.shape[0],
                                             pcds_feat.shape[1], pcds_feat.shape[2], d, size, scale, code)

@@ -160,12 +160,28 @@ def gen_e2e(ns, out):
         out["e2e_f%d_aux_sub" % i] = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].contiguous().numpy()
 
 
+def gen_losses(ns, out):
+    """Training losses (row f2): the reference's CE_OHEM (utils/criterion.py:10-28) and lovasz_softmax
+    (utils/lovasz_losses.py:147-222) on seeded logits, with the gradient of ce + 3 * lovasz."""
+    import utils.criterion as rc
+    import utils.lovasz_losses as rl
+    g = torch.Generator().manual_seed(0)
+    pred = torch.randn(2, 3, 500, 1, generator=g, requires_grad=True)
+    gt = torch.randint(0, 3, (2, 500, 1), generator=g)
+    a = rc.CE_OHEM(top_ratio=0.2, top_weight=4.0, ignore_index=0)(pred, gt)
+    b = rl.lovasz_softmax(pred, gt, ignore=0)
+    out["pred"], out["gt"] = pred.detach().numpy(), gt.numpy()
+    out["ohem"], out["lovasz"] = np.array(a.item()), np.array(b.item())
+    out["grad"] = torch.autograd.grad(a + 3 * b, pred)[0].numpy()
+
+
 def main():
     ns = ref_import.import_reference()
     torch.set_num_threads(8)
     for name, fn, needs_ns in (("ops_voxel_maxpool", gen_voxel_maxpool, True), ("ops_bilinear", gen_bilinear, True),
                                ("ops_msda", gen_msda, True), ("ops_voting", gen_voting, True),
-                               ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True)):
+                               ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True),
+                               ("losses", gen_losses, True)):
         out = {}
         fn(ns, out) if needs_ns else fn(out)
         path = os.path.join(HERE, name + ".npz")

@@ -1,0 +1,74 @@
+"""Training row (f2): deformable-attention backward against finite differences -- the check the reference's own
+test performs (deformattn/test.py:63-78, gradcheck in double) -- and one chained training step of AttNet."""
+import numpy as np
+import pytest
+import torch
+
+from streammos_amd import synth
+from streammos_amd.refapi.deformattn.functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 257])
+def test_msda_gradcheck_double(channels):
+    torch.manual_seed(3)
+    n, m, lq, p = 1, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    value = (torch.rand(n, s, m, channels, device=DEV) * 0.01).double().requires_grad_(True)
+    loc = torch.rand(n, lq, m, 2, p, 2, device=DEV).double().requires_grad_(True)
+    attn = torch.rand(n, lq, m, 2, p, device=DEV) + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, attn, 2))
+
+
+def test_msda_backward_float_matches_autograd_of_torch_formulation():
+    value, shapes, lsi, loc, attn = cases.msda_cases()["model"]
+    tv = torch.from_numpy(value).to(DEV).requires_grad_(True)
+    tl = torch.from_numpy(loc).to(DEV).requires_grad_(True)
+    ta = torch.from_numpy(attn).to(DEV).requires_grad_(True)
+    ts, ti = torch.from_numpy(shapes).to(DEV), torch.from_numpy(lsi).to(DEV)
+    g = torch.randn(value.shape[0], loc.shape[1], value.shape[2] * value.shape[3], device=DEV,
+                    generator=torch.Generator(device=DEV).manual_seed(1))
+    MSDeformAttnFunction.apply(tv, ts, ti, tl, ta, 64).backward(g)
+    got = [t.grad.clone() for t in (tv, tl, ta)]
+    for t in (tv, tl, ta):
+        t.grad = None
+    ms_deform_attn_core_pytorch(tv, ts, tl, ta).backward(g)
+    for a, b in zip(got, (tv.grad, tl.grad, ta.grad)):
+        assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6)
+
+
+def test_one_chained_training_step_runs_and_updates_weights():
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    model = model.to(DEV).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    frames = list(cases.e2e_frames(3))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    batch = {}
+    for i, f in enumerate(frames):
+        for k, v in f.items():
+            batch["%s_%d" % (k, i)] = torch.from_numpy(v).to(DEV)
+        batch["pcds_target_%d" % i] = torch.randint(0, 3, (2, cases.E2E_POINTS, 1), generator=gen).to(DEV)
+        batch["pcds_bev_target_%d" % i] = torch.randint(0, 3, (2, 256, 256, 1), generator=gen).to(DEV)
+    before = model.pred_layer.pred_layer[0].weight.detach().clone()
+    q_before = model.bev_net.query_embed.weight.detach().clone()
+    loss = model(batch)
+    assert torch.isfinite(loss) and loss.item() > 0
+    loss.backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 300 and all(torch.isfinite(g).all() for g in grads)
+    # the memory chain carries gradient back to the learned embedding of frame 0 and through the HIP sampler
+    assert model.bev_net.query_embed.weight.grad.abs().sum().item() > 0
+    assert model.bev_net.deformattn_module.deformattn_layers[0].cross_attn.sampling_offsets.weight.grad.abs().sum().item() > 0
+    assert model.point_pre.layer[0].layer[1].weight.grad.abs().sum().item() > 0        # through VoxelMaxPool backward
+    opt.step()
+    assert (model.pred_layer.pred_layer[0].weight - before).abs().max().item() > 0
+    assert (model.bev_net.query_embed.weight - q_before).abs().max().item() > 0

@@ -206,3 +206,83 @@ def test_kitti_formats_round_trip(tmp_path):
     m = kitti.MovingIoU()
     m.add(np.array([0, 1, 2, 2, 1]), np.array([2, 1, 2, 1, 1]))
     assert abs(m.result()["moving_iou"] - 0.5) < 1e-9 and abs(m.result()["static_iou"] - 2 / 3) < 1e-9
+
+
+def test_training_losses_match_reference_golden(golden):
+    from streammos_amd.refapi.models import losses
+    g = golden("losses")
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    gt = torch.from_numpy(g["gt"])
+    a = losses.ohem_cross_entropy(pred, gt, top_ratio=0.2, top_weight=4.0, ignore_index=0)
+    b = losses.lovasz_softmax(pred, gt, ignore=0)
+    assert abs(a.item() - float(g["ohem"])) <= 1e-6 * abs(float(g["ohem"]))
+    assert abs(b.item() - float(g["lovasz"])) <= 1e-6
+    grad = torch.autograd.grad(a + 3 * b, pred)[0].numpy()
+    np.testing.assert_allclose(grad, g["grad"], rtol=1e-5, atol=1e-8)
+    assert losses.lovasz_softmax(pred, torch.zeros_like(gt), ignore=0) == 0        # everything ignored
+
+
+def test_training_forward_on_cpu_with_gloo_ddp(tmp_path):
+    """Two-rank DDP (gloo) over the CPU module graph: gradients are all-reduced and both ranks end the step with
+    identical weights.  The GPU-only sampler is swapped for the debug torch formulation (as deformattn/test.py does)."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(_DDP_WORKER % ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="3"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["same_weights"] and line["loss_finite"] and line["changed"]
+
+
+_DDP_WORKER = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+from streammos_amd import preprocess, synth
+from streammos_amd.refapi import MultiScaleDeformableAttention as msda
+from streammos_amd.refapi.config import StreamMOS as cfg
+from streammos_amd.refapi.deformattn.functions import ms_deform_attn_func as fn
+from streammos_amd.refapi.models import StreamMOS
+
+# CPU stand-in for the GPU-only sampler: the debug torch formulation, differentiable through autograd
+class _Fn:
+    @staticmethod
+    def apply(value, shapes, lsi, loc, attn, step):
+        return fn.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+import streammos_amd.refapi.deformattn.modules.ms_deform_attn as mod
+mod.MSDeformAttnFunction = _Fn
+
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+torch.manual_seed(0)
+model = StreamMOS.AttNet(cfg.get_config()[2])
+model.load_state_dict(synth.seeded_state_dict(model.state_dict()))
+ddp = DDP(model.train(), find_unused_parameters=True)
+opt = torch.optim.SGD(ddp.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-3)
+spec = preprocess.VoxelSpec()
+n = 512
+scans = [synth.synthetic_scan(10 * rank + k, 8, 40) for k in range(5)]
+poses = [synth.synthetic_pose(k) for k in range(5)]
+gen = torch.Generator().manual_seed(rank)
+batch = {}
+for i in range(3):
+    idx = preprocess.window_indices(i, 5, 3)
+    s = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], n, spec, tta=False)
+    for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"):
+        batch["%%s_%%d" %% (k, i)] = torch.from_numpy(s[k])
+    batch["pcds_target_%%d" %% i] = torch.randint(0, 3, (1, n, 1), generator=gen)
+    batch["pcds_bev_target_%%d" %% i] = torch.randint(0, 3, (1, 256, 256, 1), generator=gen)
+before = model.pred_layer.pred_layer[0].weight.detach().clone()
+loss = ddp(batch)
+loss.backward()
+opt.step()
+w = model.pred_layer.pred_layer[0].weight.detach().clone()
+ws = [torch.zeros_like(w) for _ in range(2)]
+dist.all_gather(ws, w)
+if rank == 0:
+    print(json.dumps({"same_weights": bool(torch.equal(ws[0], ws[1])), "loss_finite": bool(torch.isfinite(loss)),
+                      "changed": bool((w - before).abs().max() > 0)}))
+dist.destroy_process_group()
+"""
