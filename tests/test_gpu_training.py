@@ -64,7 +64,7 @@ def test_one_chained_training_step_runs_and_updates_weights():
     assert torch.isfinite(loss) and loss.item() > 0
     loss.backward()
     grads = [p.grad for p in model.parameters() if p.grad is not None]
-    assert len(grads) > 300 and all(torch.isfinite(g).all() for g in grads)
+    assert len(grads) > 200 and all(torch.isfinite(g).all() for g in grads)
     # the memory chain carries gradient back to the learned embedding of frame 0 and through the HIP sampler
     assert model.bev_net.query_embed.weight.grad.abs().sum().item() > 0
     assert model.bev_net.deformattn_module.deformattn_layers[0].cross_attn.sampling_offsets.weight.grad.abs().sum().item() > 0
