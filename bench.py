@@ -136,15 +136,25 @@ def main():
     ap.add_argument("--no-vote", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a captured hipGraph")
     ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (not used by the driver): SMOS_BENCH_BACKEND=gloo + SMOS_BENCH_ONE_DEVICE=1 let several ranks
+    # share the single GPU of a development box to exercise the multi-rank code path
+    backend = os.environ.get("SMOS_BENCH_BACKEND", "nccl")
+    if os.environ.get("SMOS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -189,7 +199,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -236,6 +246,28 @@ def main():
             line["raw_scan_pipeline"] = {"value": round(20 / (time.perf_counter() - t1), 3), "unit": "scans/s",
                                          "note": "H2D of 3 raw scans (5.8 MB) + device preprocessing + the same step; "
                                                  "PCIe-inclusive, reported beside `value`, never as `value`"}
+        if world == 1 and args.streams > 1:
+            # configs[2]: S concurrent sequences advanced in lock step as one batch of 4*S samples
+            S = args.streams
+            ms = streaming.MultiStreamRunner(model, device, n_streams=S, vote=not args.no_vote)
+            per_stream = [make_frames(4, seq_seed=100 + q) for q in range(S)]
+            batched = []
+            for f in range(4):
+                devs = [runner.upload(per_stream[q][f][0], per_stream[q][f][1]) for q in range(S)]
+                batched.append((ms.batch_inputs(devs), [per_stream[q][f][2] for q in range(S)]))
+            for i in range(3):
+                ms.step(*batched[i % 4])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n_it = 10
+            for i in range(n_it):
+                ms.step(*batched[(3 + i) % 4])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t2
+            line["batched_streams"] = {"streams": S, "value": round(S * n_it / dt, 3), "unit": "scans/s",
+                                       "ms_per_batched_step": round(1e3 * dt / n_it, 3),
+                                       "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                                       "note": "BASELINE configs[2]; reported beside `value`, never as `value`"}
         if world == 1 and args.cpu_scans > 0:
             line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
         print(json.dumps(line), flush=True)

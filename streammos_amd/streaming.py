@@ -207,3 +207,41 @@ class StreamRunner:
                 out["voted"] = self.voter.push(dev["raw_scan"], raw, pose if pose is not None else np.eye(4))
         self.frame += 1
         return out
+
+
+class MultiStreamRunner:
+    """S independent sequences advanced in lock step as ONE batch of S x V samples (BASELINE.json configs[2]:
+    concurrent sequences on one GPU, every stream's recurrent memory and voting window resident in HBM).
+    Streams never interact: the network is batch-independent, the TTA reduce and the voting run per stream."""
+
+    def __init__(self, model, device="cuda:0", n_streams=8, vote=True):
+        self.device = torch.device(device)
+        self.model = model.to(self.device).eval()
+        self.n = n_streams
+        self.voters = [VoxelVoter(self.device) for _ in range(n_streams)] if vote else None
+        self.memory = None
+        self.frame = 0
+
+    @staticmethod
+    def batch_inputs(devs):
+        """list of per-stream uploads (StreamRunner.upload) -> one batched dict (concatenated along the TTA dim)."""
+        out = {k: torch.cat([d[k] for d in devs], 0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+        out["streams"] = [{k: d[k] for k in d if k not in out} for d in devs]
+        return out
+
+    @torch.no_grad()
+    def step(self, batched, poses):
+        batch = {k: batched[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+        pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
+        v = pred_cls.shape[0] // self.n
+        outs = []
+        for s, meta in enumerate(batched["streams"]):
+            labels = ops.tta_argmax(pred_cls[s * v:(s + 1) * v])
+            raw = torch.zeros(meta["n_raw"], dtype=torch.uint8, device=self.device)
+            raw.index_copy_(0, meta["valid_index"], labels[:meta["n_valid"]])
+            voted = []
+            if self.voters is not None and "raw_scan" in meta:
+                voted = self.voters[s].push(meta["raw_scan"], raw, poses[s])
+            outs.append({"labels": labels, "raw_labels": raw, "voted": voted})
+        self.frame += 1
+        return pred_cls, outs

@@ -250,3 +250,38 @@ def test_graph_replay_equals_eager(model):
     for (p0, l0, r0), (p1, l1, r1) in zip(res[False], res[True]):
         assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
         assert (l0 == l1).float().mean().item() >= 0.9995 and (r0 == r1).float().mean().item() >= 0.9995
+
+
+def test_concurrent_streams_equal_separate_streams(model):
+    """configs[2] in small: two sequences batched through MultiStreamRunner give each stream the labels it gets
+    when streamed alone (the network is batch-independent; MIOpen may pick another algorithm per batch size, hence a
+    tolerance on the logits instead of equality)."""
+    spec = preprocess.VoxelSpec()
+    seqs = []
+    for q in range(2):
+        scans = [synth.synthetic_scan(50 * q + k, 16, 120) for k in range(6)]
+        poses = [synth.synthetic_pose(k) for k in range(6)]
+        seqs.append((scans, poses))
+    solo = []
+    for scans, poses in seqs:
+        r = streaming.StreamRunner(model, DEV, vote=False)
+        outs = []
+        for i in range(3):
+            idx = preprocess.window_indices(i, 6, 3)
+            sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+            o = r.step(r.upload(sample, scans[i]), poses[i])
+            outs.append((o["pred_cls"].clone(), o["raw_labels"].clone()))
+        solo.append(outs)
+    ms = streaming.MultiStreamRunner(model, DEV, n_streams=2, vote=False)
+    up = streaming.StreamRunner(model, DEV, vote=False)
+    for i in range(3):
+        devs = []
+        for scans, poses in seqs:
+            idx = preprocess.window_indices(i, 6, 3)
+            sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+            devs.append(up.upload(sample, scans[i]))
+        pred, outs = ms.step(ms.batch_inputs(devs), [seqs[q][1][i] for q in range(2)])
+        for q in range(2):
+            want_pred, want_raw = solo[q][i]
+            assert (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() <= 1e-4 * want_pred.abs().max().item()
+            assert (outs[q]["raw_labels"] == want_raw).float().mean().item() >= 0.9995
