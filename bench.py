@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10, help="distinct preprocessed scans cycled through")
     ap.add_argument("--no-vote", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a captured hipGraph")
+    ap.add_argument("--split", type=int, default=1, help="with --graph: TTA groups replayed concurrently on HIP streams")
     ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
@@ -165,7 +166,7 @@ def main():
     model = StreamMOS.AttNet(cfg.get_config()[2])
     state = synth.seeded_state_dict(model.state_dict())
     model.load_state_dict(state, strict=True)
-    runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph)
+    runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph, split=args.split)
 
     frames = make_frames(args.frames, seq_seed=rank)
     dev_frames = [(runner.upload(s, raw), pose) for s, raw, pose in frames]

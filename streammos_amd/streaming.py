@@ -97,52 +97,73 @@ class VoxelVoter:
 class StreamRunner:
     """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
 
-    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False):
-        """graph=True captures the network forward + TTA reduce of a frame into two hipGraphs (first frame: learned
-        memory embedding; later frames: recurrent memory) that are replayed on static buffers -- one launch per scan
-        instead of ~180.  The per-frame voting stays outside the graph (its pose matrices are launch arguments)."""
+    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False, split=1):
+        """graph=True captures the network forward of a frame into hipGraphs (first frame: learned memory embedding;
+        later frames: recurrent memory) that are replayed on static buffers -- one launch per scan instead of ~180.
+        split=k additionally cuts the TTA batch into k independent groups (TTA variants never interact inside the
+        network) whose graphs are replayed on k HIP streams at once, so that the many small kernels of one group fill
+        the CUs the other group leaves idle.  Voting stays outside the graphs (pose matrices are launch arguments)."""
         self.device = torch.device(device)
         self.model = model.to(self.device).eval()
         self.voter = VoxelVoter(self.device, recip_quantize=recip_quantize) if vote else None
         self.use_graph = graph
+        self.split = max(1, int(split))
         self._graphs = None
         self.reset()
 
     # ---- hipGraph capture -------------------------------------------------------------------
-    def _forward(self, batch, first):
-        pred_cls, _, _, _, mem = self.model.infer(batch, 0 if first else 1, None if first else self._g_mem)
-        return pred_cls, ops.tta_argmax(pred_cls), mem
+    _KEYS = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
 
     def _capture(self, dev):
-        keys = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
-        self._g_in = {k: torch.empty_like(dev[k]) for k in keys}
-        for k in keys:
-            self._g_in[k].copy_(dev[k])
-        batch = {k: self._g_in[k].unsqueeze(0) for k in keys}
+        v = dev["pcds_xyzi"].shape[0]
+        k = self.split if v % self.split == 0 else 1
+        per = v // k
+        self._groups = []
         side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            # eager warm-up on the capture stream: MIOpen algorithm search, lazy engine build, allocator pools
-            _, _, mem = self._warm(batch)
-            self._g_mem = mem.clone()
-            for _ in range(2):
-                self._forward(batch, False)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        self._graphs = {}
-        for first in (True, False):
-            g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                pred, labels, mem = self._forward(batch, first)
-                self._g_mem.copy_(mem)
-            self._graphs[first] = (g, pred, labels)
+        for gi in range(k):
+            sl = slice(gi * per, (gi + 1) * per)
+            g_in = {key: dev[key][sl].clone() for key in self._KEYS}
+            batch = {key: g_in[key].unsqueeze(0) for key in self._KEYS}
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                # eager warm-up on a side stream: MIOpen algorithm search, lazy engine build, allocator pools
+                mem = None
+                for _ in range(2):
+                    mem = self.model.infer(batch, 0, None)[4]
+                g_mem = mem.clone()
+                for _ in range(2):
+                    self.model.infer(batch, 1, g_mem)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graphs = {}
+            for first in (True, False):
+                g = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(g):
+                    pred, _, _, _, mem = self.model.infer(batch, 0 if first else 1, None if first else g_mem)
+                    g_mem.copy_(mem)
+                graphs[first] = (g, pred)
+            self._groups.append({"in": g_in, "mem": g_mem, "graphs": graphs, "slice": sl,
+                                 "stream": torch.cuda.Stream(self.device)})
+        self._g_shape = tuple(dev["pcds_xyzi"].shape)
+        self._g_pred = torch.empty((v,) + tuple(self._groups[0]["graphs"][True][1].shape[1:]), dtype=torch.float32,
+                                   device=self.device)
+        self._graphs = True
 
-    def _warm(self, batch):
-        pred, labels, mem = None, None, None
-        for _ in range(2):
-            pred_cls, _, _, _, mem = self.model.infer(batch, 0, None)
-            labels = ops.tta_argmax(pred_cls)
-        return pred, labels, mem
+    def _replay(self, dev):
+        main = torch.cuda.current_stream(self.device)
+        first = self.frame == 0
+        for grp in self._groups:
+            for key in self._KEYS:
+                grp["in"][key].copy_(dev[key][grp["slice"]])
+        for grp in self._groups:
+            grp["stream"].wait_stream(main)
+            with torch.cuda.stream(grp["stream"]):
+                g, pred = grp["graphs"][first]
+                g.replay()
+                self._g_pred[grp["slice"]].copy_(pred)
+        for grp in self._groups:
+            main.wait_stream(grp["stream"])
+        return self._g_pred
 
     def reset(self):
         self.memory = None
@@ -183,13 +204,11 @@ class StreamRunner:
         """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
         voted = [(frame_id, int32 LUT labels)])."""
         if self.use_graph:
-            if self._graphs is None or any(self._g_in[k].shape != dev[k].shape for k in self._g_in):
+            if self._graphs is None or self._g_shape != tuple(dev["pcds_xyzi"].shape):
                 self._capture(dev)
-            for k, buf in self._g_in.items():
-                buf.copy_(dev[k])
-            g, pred_cls, labels = self._graphs[self.frame == 0]
-            g.replay()
-            self.memory = self._g_mem       # static buffers: valid until the next step()
+            pred_cls = self._replay(dev)        # static buffer: valid until the next step()
+            labels = ops.tta_argmax(pred_cls)
+            self.memory = [grp["mem"] for grp in self._groups]
         else:
             batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
             pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)

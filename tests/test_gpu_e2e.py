@@ -238,8 +238,8 @@ def test_graph_replay_equals_eager(model):
     scans = [synth.synthetic_scan(k, 16, 120) for k in range(6)]
     poses = [synth.synthetic_pose(k) for k in range(6)]
     res = {}
-    for graph in (False, True):
-        runner = streaming.StreamRunner(model, DEV, vote=False, graph=graph)
+    for graph in (False, True, 2):
+        runner = streaming.StreamRunner(model, DEV, vote=False, graph=bool(graph), split=2 if graph == 2 else 1)
         outs = []
         for i in range(4):
             idx = preprocess.window_indices(i, 6, 3)
@@ -247,9 +247,10 @@ def test_graph_replay_equals_eager(model):
             o = runner.step(runner.upload(sample, scans[i]), poses[i])
             outs.append((o["pred_cls"].clone(), o["labels"].clone(), o["raw_labels"].clone()))
         res[graph] = outs
-    for (p0, l0, r0), (p1, l1, r1) in zip(res[False], res[True]):
-        assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
-        assert (l0 == l1).float().mean().item() >= 0.9995 and (r0 == r1).float().mean().item() >= 0.9995
+    for other in (True, 2):
+        for (p0, l0, r0), (p1, l1, r1) in zip(res[False], res[other]):
+            assert (p0 - p1).abs().max().item() <= 1e-4 * p0.abs().max().item()
+            assert (l0 == l1).float().mean().item() >= 0.9995 and (r0 == r1).float().mean().item() >= 0.9995
 
 
 def test_concurrent_streams_equal_separate_streams(model):
