@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-vote", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a captured hipGraph")
     ap.add_argument("--split", type=int, default=1, help="with --graph: TTA groups replayed concurrently on HIP streams")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the encoder of frame t+1 with the decoder of frame t")
     ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
@@ -166,14 +168,15 @@ def main():
     model = StreamMOS.AttNet(cfg.get_config()[2])
     state = synth.seeded_state_dict(model.state_dict())
     model.load_state_dict(state, strict=True)
-    runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph, split=args.split)
+    runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph, split=args.split,
+                                    pipeline=not (args.no_pipeline or args.graph))
 
     frames = make_frames(args.frames, seq_seed=rank)
     dev_frames = [(runner.upload(s, raw), pose) for s, raw, pose in frames]
 
     def one_step(i):
         d, pose = dev_frames[i % len(dev_frames)]
-        return runner.step(d, pose)
+        return runner.step(d, pose, next_dev=dev_frames[(i + 1) % len(dev_frames)][0])
 
     def sync():
         torch.cuda.synchronize()

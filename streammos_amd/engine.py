@@ -222,6 +222,13 @@ class InferenceEngine:
     # ---- the network ------------------------------------------------------------------------
     @torch.no_grad()
     def stage_forward(self, point_feat, pcds_coord, pcds_sphere_coord, memory=None):
+        return self.decode(self.encode(point_feat, pcds_coord, pcds_sphere_coord), memory)
+
+    @torch.no_grad()
+    def encode(self, point_feat, pcds_coord, pcds_sphere_coord):
+        """Everything that does NOT depend on the previous frame: point MLP + input scatter, the three BEV stages
+        and both cross-view cascades (multi_view_encoder.py:393-423).  The recurrent memory only enters in
+        ``decode``, so the encoder of frame t+1 may run while frame t is still being decoded (StreamRunner pipeline)."""
         bs, t, cin, n, _ = point_feat.shape
         dev = point_feat.device
         bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
@@ -249,7 +256,15 @@ class InferenceEngine:
         self._cross_view(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:])
 
         x2 = self._run_stage(x1cat, self.res2)
-        x2 = self._temporal_fusion(x2, memory)
+        return {"x0cat": x0cat, "x1cat": x1cat, "x2": x2, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
+
+    @torch.no_grad()
+    def decode(self, enc, memory=None):
+        """Temporal fusion with the memory of the previous frame, decoder, point head (multi_view_encoder.py:426-456,
+        models/StreamMOS.py:105-113)."""
+        x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
+        bs, n = fuse.shape[0], fuse.shape[1]
+        x2 = self._temporal_fusion(enc["x2"], memory)
 
         dec_in = ops.upsample_concat([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
         y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)

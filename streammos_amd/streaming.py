@@ -97,7 +97,7 @@ class VoxelVoter:
 class StreamRunner:
     """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
 
-    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False, split=1):
+    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False, split=1, pipeline=False):
         """graph=True captures the network forward of a frame into hipGraphs (first frame: learned memory embedding;
         later frames: recurrent memory) that are replayed on static buffers -- one launch per scan instead of ~180.
         split=k additionally cuts the TTA batch into k independent groups (TTA variants never interact inside the
@@ -109,6 +109,12 @@ class StreamRunner:
         self.use_graph = graph
         self.split = max(1, int(split))
         self._graphs = None
+        # pipeline=True: only the temporal fusion needs the previous frame, so the encoder of frame t+1 (point MLP,
+        # scatters, the BEV / range-view stages: ~60 % of the work) is issued on a second HIP stream while frame t
+        # is decoded on the main one.  step() must then be given the next frame's inputs (one frame of look-ahead).
+        self.pipeline = pipeline
+        self._side = torch.cuda.Stream(self.device) if pipeline else None
+        self._pre_enc = None
         self.reset()
 
     # ---- hipGraph capture -------------------------------------------------------------------
@@ -168,6 +174,7 @@ class StreamRunner:
     def reset(self):
         self.memory = None
         self.frame = 0
+        self._pre_enc = None
         if self.voter is not None:
             self.voter.reset()
 
@@ -199,16 +206,41 @@ class StreamRunner:
         built["raw_scan"] = dev_scans[0]
         return self.step(built, poses[0])
 
+    def _pipelined(self, dev, next_dev):
+        eng = self.model._engine_for(dev["pcds_xyzi"])
+        if eng is None:
+            raise RuntimeError("StreamRunner(pipeline=True) needs the fused GPU engine (eval mode, fast_inference)")
+        main = torch.cuda.current_stream(self.device)
+        if self._pre_enc is not None and self._pre_enc[0] is dev:
+            enc = self._pre_enc[1]
+            main.wait_stream(self._side)               # encoder of this frame, issued during the previous step
+        else:
+            enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
+        self._pre_enc = None
+        if next_dev is not None:                        # encoder of the NEXT frame, concurrent with this decode
+            with torch.cuda.stream(self._side):
+                nxt = eng.encode(next_dev["pcds_xyzi"], next_dev["pcds_coord"], next_dev["pcds_sphere_coord"])
+            for t in list(nxt.values()) + [next_dev[k] for k in self._KEYS]:
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+                    t.record_stream(self._side)
+            self._pre_enc = (next_dev, nxt)
+        pred_cls, _, _, _, self.memory = eng.decode(enc, self.memory if self.frame > 0 else None)
+        return pred_cls
+
     @torch.no_grad()
-    def step(self, dev, pose=None):
+    def step(self, dev, pose=None, next_dev=None):
         """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
-        voted = [(frame_id, int32 LUT labels)])."""
+        voted = [(frame_id, int32 LUT labels)]).  next_dev: the following frame's inputs (pipeline mode)."""
         if self.use_graph:
             if self._graphs is None or self._g_shape != tuple(dev["pcds_xyzi"].shape):
                 self._capture(dev)
             pred_cls = self._replay(dev)        # static buffer: valid until the next step()
             labels = ops.tta_argmax(pred_cls)
             self.memory = [grp["mem"] for grp in self._groups]
+        elif self.pipeline:
+            pred_cls = self._pipelined(dev, next_dev)
+            labels = ops.tta_argmax(pred_cls)
         else:
             batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
             pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)

@@ -286,3 +286,31 @@ def test_concurrent_streams_equal_separate_streams(model):
             want_pred, want_raw = solo[q][i]
             assert (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() <= 1e-4 * want_pred.abs().max().item()
             assert (outs[q]["raw_labels"] == want_raw).float().mean().item() >= 0.9995
+
+
+def test_pipelined_runner_equals_plain_runner(model):
+    """pipeline=True overlaps the encoder of frame t+1 with the decoder of frame t on a second HIP stream; results
+    must equal the serial runner's (same kernels, same inputs), frame after frame, including the voting output."""
+    spec = preprocess.VoxelSpec()
+    n_frames = 6
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(n_frames + 2)]
+    poses = [synth.synthetic_pose(k) for k in range(n_frames + 2)]
+    res = {}
+    for pipe in (False, True):
+        runner = streaming.StreamRunner(model, DEV, vote=True, pipeline=pipe)
+        runner.voter.window = 3
+        devs = []
+        for i in range(n_frames):
+            idx = preprocess.window_indices(i, n_frames + 2, 3)
+            sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+            devs.append(runner.upload(sample, scans[i]))
+        outs = []
+        for i in range(n_frames):
+            o = runner.step(devs[i], poses[i], next_dev=devs[i + 1] if i + 1 < n_frames else None)
+            outs.append((o["pred_cls"].clone(), o["raw_labels"].clone(), [(f, l.clone()) for f, l in o["voted"]]))
+        torch.cuda.synchronize()
+        res[pipe] = outs
+    for (p0, r0, v0), (p1, r1, v1) in zip(res[False], res[True]):
+        assert torch.equal(p0, p1) or (p0 - p1).abs().max().item() <= 1e-6 * p0.abs().max().item()
+        assert torch.equal(r0, r1)
+        assert [f for f, _ in v0] == [f for f, _ in v1] and all(torch.equal(a[1], b[1]) for a, b in zip(v0, v1))
