@@ -22,3 +22,17 @@ def golden():
             cache[name] = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
         return cache[name]
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle runs on torch-CPU; on a shared many-core host the default (one thread per logical core, 256 on
+    the GPU boxes) oversubscribes the machine and can stall for minutes.  Cap it at the per-GPU CPU share."""
+    import torch
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(max(1, min(n, 16)))
+    yield
