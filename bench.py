@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=10, help="distinct preprocessed scans cycled through")
     ap.add_argument("--no-vote", action="store_true")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: MIOpen measures every solver once per conv shape")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a captured hipGraph")
     ap.add_argument("--split", type=int, default=1, help="with --graph: TTA groups replayed concurrently on HIP streams")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -161,6 +163,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    if args.miopen_search:
+        torch.backends.cudnn.benchmark = True
     from streammos_amd import profiling, streaming, synth
     from streammos_amd.refapi.config import StreamMOS as cfg
     from streammos_amd.refapi.models import StreamMOS
