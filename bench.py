@@ -234,7 +234,7 @@ def main():
             "path_roofline": {"bound": "hbm", "achieved": round(value / world * ALG_GB_PER_SCAN, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(value / world * ALG_GB_PER_SCAN / HBM_PEAK_GBS, 4),
                               "note": "scans/s/GPU x 11.2 GB algorithmic bytes per scan (SURVEY.md 8d)"},
-            "hip_kernel_ms_per_step": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
+            "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if world == 1:
             # PCIe-inclusive variant (never `value`): raw scans uploaded every step, preprocessing on the device
