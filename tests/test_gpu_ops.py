@@ -305,3 +305,39 @@ def test_downsample_epilogue_channels_last_kernel():
         ops.downsample_epilogue(a.contiguous(memory_format=torch.channels_last), p.contiguous(memory_format=torch.channels_last),
                                 bias, stride, out=big[:, 16:])
         assert (big[:, 16:] - want).abs().max().item() < 1e-6 and big[:, :16].abs().max().item() == 0
+
+
+def test_vote_full_size_local_map_bit_exact():
+    """A realistic local map (8 history scans + the current one, 120k points each, ~1 M points) through the packed
+    vote table against the numpy restatement of the reference's dense histogram + argmax."""
+    from streammos_amd import preprocess, synth
+    rng = np.random.Generator(np.random.PCG64(77))
+    cur_id = 12
+    scans = {k: synth.synthetic_scan(k) for k in range(cur_id - 8, cur_id + 1)}
+    preds = {k: rng.integers(0, 3, scans[k].shape[0]).astype(np.uint8) for k in scans}
+    poses = {k: synth.synthetic_pose(k) for k in scans}
+    inv_cur = np.linalg.inv(poses[cur_id])
+    table = torch.empty(512 * 512 * 30, dtype=torch.int64, device=DEV)
+    ops.vote_clear(table)
+    hist_pts, hist_lab = [], []
+    for k in range(cur_id - 1, cur_id - 9, -1):
+        ops.vote_accumulate(_t(scans[k]), _t(preds[k]), table, pose_diff=inv_cur.dot(poses[k]))
+        hist_pts.append(preprocess.pose_align(scans[k], inv_cur.dot(poses[k])))
+        hist_lab.append(preds[k])
+    ops.vote_accumulate(_t(scans[cur_id]), _t(preds[cur_id]), table)
+    got = ops.vote_resolve(_t(scans[cur_id]), _t(preds[cur_id]), table).cpu().numpy()
+    want = ops_np.vote_frame(scans[cur_id], preds[cur_id], np.concatenate(hist_pts, 0), np.concatenate(hist_lab, 0))
+    # the float64 pose product is evaluated in a fixed order on the device and in BLAS order on the host; a point whose
+    # float32 coordinate differs in the last ulp can change voxel -- allow a handful, demand exactness elsewhere
+    assert (got == want).mean() >= 0.99999
+
+
+def test_zero_sized_inputs_are_no_ops():
+    out = torch.zeros((2, 4, 8, 8), device=DEV)
+    ops.voxel_maxpool_fwd(torch.zeros((2, 4, 0), device=DEV), torch.zeros((2, 0, 2), device=DEV), out, (8, 8), (1.0, 1.0))
+    assert out.abs().max().item() == 0
+    assert ops.bilinear_gather(torch.randn(2, 4, 8, 8, device=DEV), torch.zeros((2, 0, 2), device=DEV), (1.0, 1.0)).shape == (2, 4, 0)
+    table = torch.zeros(512 * 512 * 30, dtype=torch.int64, device=DEV)
+    ops.vote_accumulate(torch.zeros((0, 4), device=DEV), torch.zeros(0, dtype=torch.uint8, device=DEV), table)
+    assert ops.vote_resolve(torch.zeros((0, 4), device=DEV), torch.zeros(0, dtype=torch.uint8, device=DEV), table).numel() == 0
+    assert table.abs().max().item() == 0
