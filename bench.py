@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=10, help="distinct preprocessed scans cycled through")
     ap.add_argument("--no-vote", action="store_true")
+    ap.add_argument("--layout", default="cl", choices=["cl", "nchw"], help="feature-map layout of the fused engine")
     ap.add_argument("--miopen-search", action="store_true",
                     help="torch.backends.cudnn.benchmark = True: MIOpen measures every solver once per conv shape")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a captured hipGraph")
@@ -172,6 +173,7 @@ def main():
     model = StreamMOS.AttNet(cfg.get_config()[2])
     state = synth.seeded_state_dict(model.state_dict())
     model.load_state_dict(state, strict=True)
+    model.engine_layout = args.layout
     runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph, split=args.split,
                                     pipeline=not (args.no_pipeline or args.graph))
 

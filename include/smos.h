@@ -221,6 +221,30 @@ int smos_msda_bwd(const void* grad_out, const void* value, const int64_t* spatia
                   void* grad_attn_weight, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
                   int32_t dtype, smos_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Channels-last ("cl") engine kernels (csrc/cl_kernels.hip).  A map is [B, H, W, C] with C innermost; every tensor
+ * argument has its own row pitch (elements between consecutive pixels / points), so it may be a channel slice of a
+ * wider buffer.  P = number of rows (B*H*W).  All pointers 16-byte aligned, C and pitches multiples of 4.
+ */
+int smos_bias_act_cl(const float* x, int64_t x_pitch, const float* bias, const float* res, int64_t res_pitch, float* out,
+                     int64_t out_pitch, int64_t P, int64_t C, int32_t act, smos_stream_t stream);
+int smos_downsample_epilogue_cl(const float* a, int64_t a_pitch, const float* p, int64_t p_pitch, const float* bias, float* out,
+                                int64_t out_pitch, int64_t B, int64_t C, int64_t H, int64_t W, int32_t stride,
+                                smos_stream_t stream);
+/* ws: device scratch of at least B*C*65 floats (deterministic two-stage column sums + the gates). */
+int smos_channel_gate_residual_cl(const float* y, int64_t y_pitch, const float* bias, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
+                                  int64_t out_pitch, float* ws, int64_t ws_floats, int64_t B, int64_t C, int64_t Cr, int64_t HW,
+                                  smos_stream_t stream);
+int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
+                            const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
+                            smos_stream_t stream);
+/* smos_gather_scatter with a channels-last source grid [B,Hg,Wg,*] and target [B,Ho,Wo,*]; C is 32 or 64. */
+int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
+                           const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch, float* pts_out,
+                           int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
+                           int64_t Wo, smos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

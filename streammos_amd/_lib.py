@@ -37,6 +37,11 @@ SIGNATURES = {
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],
     "smos_prep_emit": [vp, vp, vp, i64, i32, i32, i64, i32, c_f32p, c_f32p, c_f64p, c_i64p, c_f64p, vp, vp, vp, vp],
     "smos_prep_unpad_labels": [vp, i64, vp, vp, i64, vp, vp],
+    "smos_bias_act_cl": [vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, vp],
+    "smos_downsample_epilogue_cl": [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i64, i32, vp],
+    "smos_channel_gate_residual_cl": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, vp],
+    "smos_upsample_concat_cl": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
+    "smos_gather_scatter_cl": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }
 

@@ -44,8 +44,17 @@ class _Obj:
         self.__dict__.update(kw)
 
 
+def _cl_w(w):
+    return w.contiguous(memory_format=torch.channels_last)
+
+
 class InferenceEngine:
-    def __init__(self, net):
+    def __init__(self, net, layout="cl"):
+        """layout "cl": every feature map channels-last (default; fastest under MIOpen's solver search and the natural
+        layout of the scatters and of the attention tokens); "nchw": the first version of the engine, kept for A/B."""
+        if layout not in ("cl", "nchw"):
+            raise ValueError("layout must be 'cl' or 'nchw'")
+        self.layout = layout
         self.device = next(net.parameters()).device
         self.bev_hw = tuple(net.bev_wl_shape)
         enc = net.bev_net
@@ -96,6 +105,16 @@ class InferenceEngine:
         p = net.pred_layer.pred_layer[0]
         self.pred = (p.weight.detach().contiguous(), p.bias.detach().contiguous())
         self.sums_ws = torch.zeros(4096, dtype=torch.float32, device=self.device)
+        self.gate_ws = torch.zeros(65 * 4096, dtype=torch.float32, device=self.device)
+        if layout == "cl":
+            for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
+                for p in blocks:
+                    for k in ("wa", "wp", "wb", "wc", "w1", "w2"):
+                        if hasattr(p, k):
+                            setattr(p, k, _cl_w(getattr(p, k)))
+            self.conv_1 = (_cl_w(self.conv_1[0]), self.conv_1[1])
+            self.conv_2 = (_cl_w(self.conv_2[0]), self.conv_2[1])
+            self.aux = (_cl_w(self.aux[0]), self.aux[1], self.aux[2])
         self._shapes = None
         self._lsi = None
         self._hw = None
@@ -189,7 +208,7 @@ class InferenceEngine:
         ops.gather_scatter(rv, sphere, scale, bev_xy, scale, out=back_cl, pts_out=point_rows)
         ops.nhwc_to_nchw(back_cl, back)
 
-    def _temporal_fusion(self, x2, memory):
+    def _temporal_fusion(self, x2, memory, channels_last=False):
         """DeformAttnModule (multi_view_encoder.py:426-439, 245-321): the memory stream queries the current map."""
         b, c, hh, ww = x2.shape
         dev = x2.device
@@ -201,11 +220,12 @@ class InferenceEngine:
             xs = (torch.arange(ww, dtype=torch.float32, device=dev) + 0.5) / ww
             self._ref = torch.stack((xs[None, :].expand(hh, ww), ys[:, None].expand(hh, ww)), -1).reshape(1, hh * ww, 1, 1, 1, 2)
             self._norm = torch.tensor([ww, hh], dtype=torch.float32, device=dev)
-        src = x2.flatten(2).transpose(1, 2)
+        # a channels-last [B,C,H,W] map is already the [B, H*W, C] token matrix: the permute + reshape below is a view
+        src = x2.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
         if memory is None:
             query = self.query_embed.unsqueeze(0).expand(b, -1, -1)
         else:
-            query = memory.flatten(2).transpose(1, 2)
+            query = memory.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
         lq = hh * ww
         for L in self.layers:
             h, p = L.heads, L.points
@@ -218,6 +238,8 @@ class InferenceEngine:
             query = F.layer_norm(query + F.linear(sampled, *L.out), (c,), *L.norm1)
             ffn = F.linear(F.relu(F.linear(query, *L.lin1)), *L.lin2)
             query = F.layer_norm(query + ffn, (c,), *L.norm2)
+        if channels_last:
+            return query.contiguous().view(b, hh, ww, c).permute(0, 3, 1, 2)
         return query.transpose(1, 2).reshape(b, c, hh, ww).contiguous()
 
     # ---- the network ------------------------------------------------------------------------
@@ -233,11 +255,96 @@ class InferenceEngine:
 
     def encode(self, point_feat, pcds_coord, pcds_sphere_coord):
         with torch.no_grad(), self._conv_flags():
+            if self.layout == "cl":
+                return self._encode_cl(point_feat, pcds_coord, pcds_sphere_coord)
             return self._encode(point_feat, pcds_coord, pcds_sphere_coord)
 
     def decode(self, enc, memory=None):
         with torch.no_grad(), self._conv_flags():
+            if self.layout == "cl":
+                return self._decode_cl(enc, memory)
             return self._decode(enc, memory)
+
+    # ---- channels-last path -----------------------------------------------------------------------
+    def _block_cl(self, x, p, out=None):
+        if p.kind == "down":
+            a = F.conv2d(x, p.wa, None, p.stride, 1)
+            q = F.conv2d(x, p.wp)
+            return ops.downsample_epilogue_cl(a, q, p.bias, p.stride, out=out if out is not None else a)
+        if p.kind == "unbalance":
+            b, c, h, w = x.shape
+            both = ops.empty_cl(b, 2 * c, h, w, x.device)
+            ops.bias_act_cl(F.conv2d(x, p.wa, None, 1, p.pa), p.ba, RELU, out=both[:, :c])
+            ops.bias_act_cl(F.conv2d(x, p.wb, None, 1, p.pb), p.bb, RELU, out=both[:, c:])
+            y = F.conv2d(both, p.wc, None, 1, 1)
+            return ops.bias_act_cl(y, p.bc, RELU, out=out if out is not None else y, residual=x)
+        y = F.conv2d(x, p.w1, None, 1, 1)
+        ops.bias_act_cl(y, p.b1, RELU, out=y)
+        y2 = F.conv2d(y, p.w2, None, 1, 1)
+        dst = out if out is not None else y2
+        if p.att:
+            need = 65 * y2.shape[0] * y2.shape[1]
+            if need > self.gate_ws.numel():
+                self.gate_ws = torch.zeros(need, dtype=torch.float32, device=y2.device)
+            return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.gate_ws, out=dst)
+        return ops.bias_act_cl(y2, p.b2, RELU, out=dst, residual=x)
+
+    def _stage_cl(self, x, blocks, out=None):
+        for i, p in enumerate(blocks):
+            x = self._block_cl(x, p, out if i == len(blocks) - 1 else None)
+        return x
+
+    def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None):
+        """B2P gather + P2R scatter, range-view convs, R2P gather + P2B scatter straight into cat_buf[:, c:]
+        (multi_view_encoder.py:395-405 / :410-420); everything channels-last, nothing transposed."""
+        b = cat_buf.shape[0]
+        rv = ops.empty_cl(b, c, rv_hw[0], rv_hw[1], cat_buf.device, zero=True)
+        ops.gather_scatter_cl(cat_buf[:, :c], bev_xy, scale, sphere, scale, out=rv)
+        rv = self._stage_cl(rv, rv_blocks)
+        back = cat_buf[:, c:]
+        back.zero_()
+        ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows)
+
+    def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord):
+        bs, t, cin, n, _ = point_feat.shape
+        dev = point_feat.device
+        bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
+        sphere = pcds_sphere_coord[:, 0, :, :, 0].contiguous()
+        cpt = self.pp2[0].shape[0]
+        hb, wb = self.bev_hw
+        c_dec, c1 = self.conv_2[0].shape[0], self.res1_bev[-1].w2.shape[0]
+        o1, o2 = cpt, cpt + c_dec
+        fuse = torch.empty((bs, n, cpt + c_dec + c1), dtype=torch.float32, device=dev)
+        bev_cl = torch.empty((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
+        ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
+                             pts_out=fuse[:, :, :o1], zero_fill=True)
+        c0 = self.header_bev[-1].w2.shape[0]
+        x0cat = ops.empty_cl(bs, 2 * c0, hb // 2, wb // 2, dev)
+        self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
+        self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
+        x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
+        self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])
+        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:])
+        x2 = self._stage_cl(x1cat, self.res2)
+        return {"x0cat": x0cat, "x1cat": x1cat, "x2": x2, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
+
+    def _decode_cl(self, enc, memory=None):
+        x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
+        bs, n = fuse.shape[0], fuse.shape[1]
+        x2 = self._temporal_fusion(enc["x2"], memory, channels_last=True)
+        dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
+        y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
+        ops.bias_act_cl(y, self.conv_1[1], LEAKY, out=y)
+        bev_feat = F.conv2d(y, self.conv_2[0], None, 1, 1)
+        ops.bias_act_cl(bev_feat, self.conv_2[1], LEAKY, out=bev_feat)
+        aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
+        k = self.aux[2]
+        ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
+        z = self._linear_relu(fuse.view(bs * n, -1), self.post1)
+        z = self._linear_relu(z, self.post2)
+        pred = torch.addmm(self.pred[1], z, self.pred[0].view(self.pred[0].shape[0], -1).t())
+        pred = pred.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
+        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
 
     def _encode(self, point_feat, pcds_coord, pcds_sphere_coord):
         """Everything that does NOT depend on the previous frame: point MLP + input scatter, the three BEV stages

@@ -364,3 +364,108 @@ def nhwc_to_nchw(src, dst):
         rc = lib.smos_nhwc_to_nchw(src.data_ptr(), dst.data_ptr(), db, dc, b, c, hw, _stream(src))
     _lib.check(rc, "smos_nhwc_to_nchw")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------
+# channels-last engine kernels: tensors are logical [B, C, H, W] with channels_last strides (possibly a channel
+# slice of a wider channels-last buffer)
+# ---------------------------------------------------------------------------------------------
+def empty_cl(b, c, h, w, device, zero=False):
+    make = torch.zeros if zero else torch.empty
+    return make((b, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def _cl(name, t):
+    """row pitch of a channels-last [B,C,H,W] view (C innermost, rows back to back over B*H*W)."""
+    b, c, h, w = t.shape
+    pitch = t.stride(3)
+    if t.stride(1) != 1 or t.stride(2) != w * pitch or (b > 1 and t.stride(0) != h * w * pitch) or pitch < c:
+        raise RuntimeError("%s: expected a channels-last [B,C,H,W] view, got shape %s strides %s" % (name, tuple(t.shape), t.stride()))
+    return pitch
+
+
+def bias_act_cl(x, bias, act, out=None, residual=None):
+    _require_cuda("bias_act_cl", x, bias, out, residual)
+    b, c, h, w = x.shape
+    if out is None:
+        out = empty_cl(b, c, h, w, x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.smos_bias_act_cl(x.data_ptr(), _cl("bias_act_cl", x), bias.data_ptr() if bias is not None else None,
+                                  residual.data_ptr() if residual is not None else None,
+                                  _cl("bias_act_cl", residual) if residual is not None else 0, out.data_ptr(),
+                                  _cl("bias_act_cl", out), b * h * w, c, act, _stream(x))
+    _lib.check(rc, "smos_bias_act_cl")
+    return out
+
+
+def downsample_epilogue_cl(a, p, bias, stride, out=None):
+    _require_cuda("downsample_epilogue_cl", a, p, bias, out)
+    b, c, h, w = p.shape
+    if out is None:
+        out = empty_cl(b, c, a.shape[2], a.shape[3], a.device)
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        rc = lib.smos_downsample_epilogue_cl(a.data_ptr(), _cl("downsample_epilogue_cl", a), p.data_ptr(),
+                                             _cl("downsample_epilogue_cl", p), bias.data_ptr(), out.data_ptr(),
+                                             _cl("downsample_epilogue_cl", out), b, c, h, w, stride, _stream(a))
+    _lib.check(rc, "smos_downsample_epilogue_cl")
+    return out
+
+
+def channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xres, ws, out=None):
+    _require_cuda("channel_gate_residual_cl", y, bias, w1, b1, w2, b2, xres, ws, out)
+    b, c, h, w = y.shape
+    if out is None:
+        out = empty_cl(b, c, h, w, y.device)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        rc = lib.smos_channel_gate_residual_cl(y.data_ptr(), _cl("channel_gate_residual_cl", y), bias.data_ptr(), w1.data_ptr(),
+                                               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), xres.data_ptr(),
+                                               _cl("channel_gate_residual_cl", xres), out.data_ptr(),
+                                               _cl("channel_gate_residual_cl", out), ws.data_ptr(), ws.numel(), b, c, w1.shape[0],
+                                               h * w, _stream(y))
+    _lib.check(rc, "smos_channel_gate_residual_cl")
+    return out
+
+
+def upsample_concat_cl(sources, size):
+    import ctypes
+    _require_cuda("upsample_concat_cl", *sources)
+    b = sources[0].shape[0]
+    ctot = sum(s.shape[1] for s in sources)
+    out = empty_cl(b, ctot, size[0], size[1], sources[0].device)
+    ptrs = (ctypes.c_void_p * len(sources))(*[s.data_ptr() for s in sources])
+    lib = _lib.load()
+    with torch.cuda.device(out.device):
+        rc = lib.smos_upsample_concat_cl(ptrs, _lib.i64_array([s.shape[1] for s in sources]),
+                                         _lib.i64_array([s.shape[2] for s in sources]),
+                                         _lib.i64_array([s.shape[3] for s in sources]),
+                                         _lib.i64_array([_cl("upsample_concat_cl", s) for s in sources]), len(sources),
+                                         out.data_ptr(), b, size[0], size[1], _stream(out))
+    _lib.check(rc, "smos_upsample_concat_cl")
+    return out
+
+
+def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None):
+    """grid: channels-last [B,C,Hg,Wg] view; out: channels-last [B,C,Ho,Wo] view, zero-filled (or None);
+    pts_out: [B,N,C] rows (or None)."""
+    _require_cuda("gather_scatter_cl", grid, gcoord, scoord, out, pts_out)
+    b, c, hg, wg = grid.shape
+    n, kg = gcoord.shape[1], gcoord.shape[2]
+    ho = wo = ks = op = 0
+    if out is not None:
+        ho, wo, ks, op = out.shape[2], out.shape[3], scoord.shape[2], _cl("gather_scatter_cl", out)
+    po_b = po_n = 0
+    if pts_out is not None:
+        po_b, po_n = _rows("gather_scatter_cl", pts_out, c)
+    lib = _lib.load()
+    label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d]" % (b, c, hg, wg, n, ho, wo)
+    with torch.cuda.device(grid.device), profiling.span(label):
+        rc = lib.smos_gather_scatter_cl(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
+                                        _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
+                                        _lib.f32_array(sscale) if out is not None else None,
+                                        out.data_ptr() if out is not None else None, op,
+                                        pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, c, hg, wg, n, ho, wo,
+                                        _stream(grid))
+    _lib.check(rc, "smos_gather_scatter_cl")

@@ -37,6 +37,7 @@ class AttNet(nn.Module):
         self.point_feat_out_channels = pModel.point_feat_out_channels
         self.build_network()
         self.fast_inference = True      # eval-mode GPU inference runs the fused engine (streammos_amd/engine.py)
+        self.engine_layout = "cl"       # "cl" (channels-last, default) or "nchw"
         self._engine = None
 
     def build_network(self):
@@ -78,9 +79,9 @@ class AttNet(nn.Module):
     def _engine_for(self, tensor):
         if not self.fast_inference or self.training or not tensor.is_cuda or torch.is_grad_enabled():
             return None
-        if self._engine is None or self._engine.device != tensor.device:
+        if self._engine is None or self._engine.device != tensor.device or self._engine.layout != self.engine_layout:
             from ... import engine
-            self._engine = engine.InferenceEngine(self)
+            self._engine = engine.InferenceEngine(self, layout=self.engine_layout)
         return self._engine
 
     # ------------------------------------------------------------------------------------

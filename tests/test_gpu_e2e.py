@@ -100,8 +100,9 @@ def test_fused_engine_equals_module_graph(model):
     same weights on the same GPU: identical function, differences only from BN folding / summation order."""
     frames = list(cases.e2e_frames(2))
     outs = {}
-    for fast in (False, True):
-        model.fast_inference = fast
+    for fast in (False, True, "nchw"):
+        model.fast_inference = bool(fast)
+        model.engine_layout = "nchw" if fast == "nchw" else "cl"
         memory = None
         res = []
         with torch.no_grad():
@@ -110,12 +111,13 @@ def test_fused_engine_equals_module_graph(model):
                 pred, a0, a1, a2, memory = model.infer(tb, i, memory)
                 res.append((pred, a0, a1, a2, memory))
         outs[fast] = res
-    model.fast_inference = True
+    model.fast_inference, model.engine_layout = True, "cl"
     assert model._engine is not None
-    for slow, fast in zip(outs[False], outs[True]):
-        for a, b in zip(slow, fast):
-            assert a.shape == b.shape
-            assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
+    for variant in (True, "nchw"):
+        for slow, fast in zip(outs[False], outs[variant]):
+            for a, b in zip(slow, fast):
+                assert a.shape == b.shape
+                assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
 
 
 def test_engine_is_dropped_when_weights_change(model):

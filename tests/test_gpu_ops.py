@@ -341,3 +341,67 @@ def test_zero_sized_inputs_are_no_ops():
     ops.vote_accumulate(torch.zeros((0, 4), device=DEV), torch.zeros(0, dtype=torch.uint8, device=DEV), table)
     assert ops.vote_resolve(torch.zeros((0, 4), device=DEV), torch.zeros(0, dtype=torch.uint8, device=DEV), table).numel() == 0
     assert table.abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------
+# channels-last engine kernels
+# ------------------------------------------------------------------------------------------
+def _to_cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def test_channels_last_elementwise_kernels_against_torch():
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    # bias_act_cl into a channel slice of a wider buffer, with a residual that is itself a slice
+    x, res, bias = _to_cl(r(3, 32, 10, 12)), _to_cl(r(3, 64, 10, 12)), r(32)
+    big = ops.empty_cl(3, 96, 10, 12, DEV, zero=True)
+    for act, fn in ((0, lambda t: t), (1, torch.relu), (2, lambda t: F.leaky_relu(t, 0.01))):
+        ops.bias_act_cl(x, bias, act, out=big[:, 32:64], residual=res[:, 16:48])
+        want = fn(x + bias[None, :, None, None] + res[:, 16:48])
+        assert (big[:, 32:64] - want).abs().max().item() < 1e-6
+        assert big[:, :32].abs().max().item() == 0 and big[:, 64:].abs().max().item() == 0
+    # downsample epilogue
+    for stride, hw in ((2, (32, 48)), (1, (8, 64)), (2, (31, 17))):
+        p, bias = _to_cl(r(2, 32, *hw)), r(32)
+        a = _to_cl(r(2, 32, (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1))
+        want = torch.relu(a + bias[None, :, None, None] + F.max_pool2d(p, 3, stride, 1))
+        got = ops.downsample_epilogue_cl(a, p, bias, stride)
+        assert (got - want).abs().max().item() < 1e-6
+    # channel gate + residual
+    for c, hw in ((32, (16, 40)), (128, (64, 64))):
+        y, xr, bias = _to_cl(r(2, c, *hw)), _to_cl(r(2, c, *hw)), r(c)
+        w1, b1, w2, b2 = r(c // 4, c), r(c // 4), r(c, c // 4), r(c)
+        z = y + bias[None, :, None, None]
+        g = torch.sigmoid(F.linear(torch.relu(F.linear(z.mean((2, 3)), w1, b1)), w2, b2))
+        want = torch.relu(z * g[:, :, None, None] + xr)
+        got = ops.channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xr, torch.zeros(65 * 2 * c, device=DEV))
+        assert (got - want).abs().max().item() < 2e-5
+    # upsample + concat
+    a, b, c = _to_cl(r(2, 8, 16, 24)), _to_cl(r(2, 12, 8, 12)), _to_cl(r(2, 4, 4, 6))
+    want = torch.cat([F.interpolate(t, size=(16, 24), mode="bilinear", align_corners=True) for t in (a, b, c)], 1)
+    got = ops.upsample_concat_cl([a, b, c], (16, 24))
+    assert torch.equal(got[:, :8], a) and (got - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("c,hw_g,hw_o,sg,ss", [(32, (64, 64), (8, 256), (0.5, 0.5), (0.5, 0.5)),
+                                              (64, (16, 128), (32, 32), (0.25, 0.25), (0.25, 0.25))])
+def test_gather_scatter_channels_last_against_unfused_ops(c, hw_g, hw_o, sg, ss):
+    gen = torch.Generator(device="cpu").manual_seed(37)
+    b, n = 2, 5000 + 13
+    wide = _to_cl(torch.relu(torch.randn((b, 2 * c) + hw_g, generator=gen)).to(DEV))
+    grid = wide[:, c:]                                                        # channel slice of a wider cl buffer
+    gcoord = _model_like_coords(gen, b, n, hw_g[0] / sg[0], hw_g[1] / sg[1]).to(DEV)
+    scoord = _model_like_coords(gen, b, n, hw_o[0] / ss[0], hw_o[1] / ss[1]).to(DEV)
+    target = ops.empty_cl(b, 2 * c, hw_o[0], hw_o[1], DEV, zero=True)
+    rows = torch.zeros((b, n, c + 8), device=DEV)
+    ops.gather_scatter_cl(grid, gcoord, sg, scoord, ss, out=target[:, c:], pts_out=rows[:, :, 8:])
+    pts = ops.bilinear_gather(grid.contiguous(), gcoord, sg)
+    want = torch.zeros((b, c) + hw_o, device=DEV)
+    ops.voxel_maxpool_fwd(pts, scoord, want, hw_o, ss)
+    assert (rows[:, :, 8:] - pts.permute(0, 2, 1)).abs().max().item() <= 1e-6
+    assert (target[:, c:] - want).abs().max().item() <= 1e-6 and target[:, :c].abs().max().item() == 0
+    rows2 = torch.zeros((b, n, c), device=DEV)
+    ops.gather_scatter_cl(grid, gcoord, sg, pts_out=rows2)
+    assert torch.equal(rows2, rows[:, :, 8:])
