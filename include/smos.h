@@ -231,7 +231,7 @@ int smos_bias_act_cl(const float* x, int64_t x_pitch, const float* bias, const f
 int smos_downsample_epilogue_cl(const float* a, int64_t a_pitch, const float* p, int64_t p_pitch, const float* bias, float* out,
                                 int64_t out_pitch, int64_t B, int64_t C, int64_t H, int64_t W, int32_t stride,
                                 smos_stream_t stream);
-/* ws: device scratch of at least B*C*65 floats (deterministic two-stage column sums + the gates). */
+/* ws: device scratch of at least B*C*(ceil(HW/512)+1) floats (deterministic two-stage column sums + the gates). */
 int smos_channel_gate_residual_cl(const float* y, int64_t y_pitch, const float* bias, const float* w1, const float* b1,
                                   const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
                                   int64_t out_pitch, float* ws, int64_t ws_floats, int64_t B, int64_t C, int64_t Cr, int64_t HW,

@@ -80,23 +80,28 @@ __global__ __launch_bounds__(kBlock) void downsample_epilogue_cl2(const float* _
 }
 
 // ---- channel attention: deterministic column sums -> gate MLP -> gated residual -------------------------
-// partial[b][chunk][c] = sum over the chunk's pixels of y[b, p, c]      (block = kBlock/C pixel lanes x C channels)
-__global__ __launch_bounds__(kBlock) void colsum_partial(const float* __restrict__ y, int64_t yp, int C, int64_t HW,
-                                                         int chunks, float* __restrict__ partial) {
-  __shared__ float red[kBlock];
+// partial[b][chunk][c] = sum over the chunk's pixels of y[b, p, c].  A block is (256 / (C/4)) pixel lanes x C/4
+// float4 columns; fixed chunking and a fixed in-block order keep the sums run-to-run deterministic.
+__global__ __launch_bounds__(kBlock) void colsum_partial(const float* __restrict__ y, int64_t yp, int C4, int64_t HW,
+                                                         int64_t per, int chunks, float* __restrict__ partial) {
+  __shared__ float4 red[kBlock];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = kBlock / C;
-  const int64_t per = (HW + chunks - 1) / chunks;
+  const int q = threadIdx.x % C4, pl = threadIdx.x / C4, npl = kBlock / C4;
   const int64_t p0 = (int64_t)chunk * per, p1 = min(HW, p0 + per);
-  float acc = 0.0f;
-  if (pl < npl)
-    for (int64_t p = p0 + pl; p < p1; p += npl) acc += y[((int64_t)b * HW + p) * yp + c];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t p = p0 + pl; p < p1; p += npl) {
+    const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)b * HW + p) * yp + q * 4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (pl == 0) {
-    float s = 0.0f;
-    for (int k = 0; k < npl; ++k) s += red[k * C + c];
-    partial[((int64_t)b * chunks + chunk) * C + c] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < npl; ++k) {
+      const float4 v = red[k * C4 + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((int64_t)b * chunks + chunk) * C4 * 4 + q * 4) = s;
   }
 }
 
@@ -324,14 +329,14 @@ extern "C" int smos_channel_gate_residual_cl(const float* y, int64_t y_pitch, co
   SMOS_REQUIRE(y && bias && w1 && b1 && w2 && b2 && xres && out && ws, "channel_gate_residual_cl: null pointer");
   SMOS_REQUIRE(al16(y) && al16(xres) && al16(out) && al16(bias) && al16(ws) && y_pitch % 4 == 0 && res_pitch % 4 == 0 &&
                    out_pitch % 4 == 0, "channel_gate_residual_cl: 16-byte alignment required");
-  int chunks = (int)((HW + 1023) / 1024);
-  if (chunks > 64) chunks = 64;
+  const int64_t per = 512;
+  const int chunks = (int)((HW + per - 1) / per);
   SMOS_REQUIRE(ws_floats >= B * C * (chunks + 1), "channel_gate_residual_cl: workspace too small (%lld floats needed)",
                (long long)(B * C * (chunks + 1)));
   float* partial = ws;
   float* gate = ws + B * C * chunks;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial, dim3(chunks, (unsigned)B), dim3(kBlock), 0, s, y, y_pitch, (int)C, HW, chunks, partial);
+  hipLaunchKernelGGL(colsum_partial, dim3(chunks, (unsigned)B), dim3(kBlock), 0, s, y, y_pitch, (int)(C / 4), HW, per, chunks, partial);
   hipLaunchKernelGGL(gate_mlp, dim3((unsigned)B), dim3(kBlock), 0, s, (const float*)partial, chunks, bias, w1, b1, w2, b2, (int)C,
                      (int)Cr, HW, gate);
   hipLaunchKernelGGL(gate_apply_cl, dim3(grid_for(B * HW * (C / 4), kBlock, 256 * 16)), dim3(kBlock), 0, s, y, y_pitch, bias,

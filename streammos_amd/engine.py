@@ -283,7 +283,7 @@ class InferenceEngine:
         y2 = F.conv2d(y, p.w2, None, 1, 1)
         dst = out if out is not None else y2
         if p.att:
-            need = 65 * y2.shape[0] * y2.shape[1]
+            need = (y2.shape[2] * y2.shape[3] // 512 + 2) * y2.shape[0] * y2.shape[1]
             if need > self.gate_ws.numel():
                 self.gate_ws = torch.zeros(need, dtype=torch.float32, device=y2.device)
             return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.gate_ws, out=dst)

@@ -376,8 +376,9 @@ def test_channels_last_elementwise_kernels_against_torch():
         z = y + bias[None, :, None, None]
         g = torch.sigmoid(F.linear(torch.relu(F.linear(z.mean((2, 3)), w1, b1)), w2, b2))
         want = torch.relu(z * g[:, :, None, None] + xr)
-        got = ops.channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xr, torch.zeros(65 * 2 * c, device=DEV))
-        assert (got - want).abs().max().item() < 2e-5
+        got = ops.channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xr, torch.zeros((hw[0] * hw[1] // 512 + 2) * 2 * c, device=DEV))
+        # N(0,1) gate weights over up to 128 channels: the pre-sigmoid sums are O(30); float32 summation order
+        assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
     # upsample + concat
     a, b, c = _to_cl(r(2, 8, 16, 24)), _to_cl(r(2, 12, 8, 12)), _to_cl(r(2, 4, 4, 6))
     want = torch.cat([F.interpolate(t, size=(16, 24), mode="bilinear", align_corners=True) for t in (a, b, c)], 1)
