@@ -46,7 +46,7 @@ def algorithmic_bytes(label):
         b, t, n = (int(v) for v in src.split("x"))
         cells = int(np.prod([int(v) for v in dst.split("x")]))
         return 4 * (b * t * 7 * n + b * t * n * 2 + b * cells * t * 64 + b * n * 64)
-    if name == "gather_scatter":
+    if name in ("gather_scatter", "gather_scatter_cl"):
         src, n, dst = dims.split("->")
         b, c, h, w = (int(v) for v in src.split("x"))
         cells = int(np.prod([int(v) for v in dst.split("x")]))

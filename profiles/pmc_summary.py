@@ -1,6 +1,6 @@
 """HBM traffic per launch of the hand-written point kernels from two rocprofv3 --pmc passes.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <fetch_dir> -- python3 bench.py --steps 3 --warmup 2 --frames 3 --cpu-scans 0
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <fetch_dir> -- python3 bench.py --steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-pipeline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <write_dir> -- python3 bench.py ... (same)
     python profiles/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/pmc_traffic.json
 
@@ -15,9 +15,9 @@ import csv
 import json
 import sys
 
-GS_ORDER = ["gather_scatter[4x32x256x256->160000->32x1024]", "gather_scatter[4x32x32x1024->160000->256x256]",
-            "gather_scatter[4x64x128x128->160000->16x512]", "gather_scatter[4x64x16x512->160000->128x128]",
-            "gather_scatter[4x64x256x256->160000->0x0]"]
+GS_ORDER = ["gather_scatter_cl[4x32x256x256->160000->32x1024]", "gather_scatter_cl[4x32x32x1024->160000->256x256]",
+            "gather_scatter_cl[4x64x128x128->160000->16x512]", "gather_scatter_cl[4x64x16x512->160000->128x128]",
+            "gather_scatter_cl[4x64x256x256->160000->0x0]"]
 
 
 def per_label(path, counter):
@@ -31,7 +31,7 @@ def per_label(path, counter):
             out["pointnet_scatter[4x3x160000->512x512]:kernel"].append(v)
         elif "FillFunctor" in k and r["Grid_Size"] == "50331648":
             out["pointnet_scatter[4x3x160000->512x512]:zero_fill"].append(v)
-        elif "gather_scatter" in k:
+        elif "gather_scatter_cl" in k:
             out[GS_ORDER[gs % 5]].append(v)
             gs += 1
     return {k: sum(v) / len(v) for k, v in out.items()}
