@@ -38,6 +38,7 @@ class AttNet(nn.Module):
         self.build_network()
         self.fast_inference = True      # eval-mode GPU inference runs the fused engine (streammos_amd/engine.py)
         self.engine_layout = "cl"       # "cl" (channels-last, default) or "nchw"
+        self.engine_miopen_search = True
         self._engine = None
 
     def build_network(self):
@@ -82,6 +83,7 @@ class AttNet(nn.Module):
         if self._engine is None or self._engine.device != tensor.device or self._engine.layout != self.engine_layout:
             from ... import engine
             self._engine = engine.InferenceEngine(self, layout=self.engine_layout)
+        self._engine.miopen_search = self.engine_miopen_search
         return self._engine
 
     # ------------------------------------------------------------------------------------

@@ -121,6 +121,12 @@ class StreamRunner:
     _KEYS = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
 
     def _capture(self, dev):
+        # capture-safe engine configuration: under MIOpen's solver search the channels-last convs resolve to
+        # composable-kernel grouped-conv solvers whose argument staging does not survive graph replay (observed: 2 %
+        # wrong logits); the NCHW engine with MIOpen's default (immediate-mode) solvers replays bit-exactly.
+        self.model.engine_layout = "nchw"
+        self.model.engine_miopen_search = False
+        self.model.invalidate_engine()
         v = dev["pcds_xyzi"].shape[0]
         k = self.split if v % self.split == 0 else 1
         per = v // k
