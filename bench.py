@@ -24,6 +24,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak (no xf32/TF32 on gfx950)
+ALG_TFLOP_PER_SCAN = 0.53        # 133 GFLOP/sample x 4 TTA samples
 ALG_GB_PER_SCAN = 11.2           # 2.806 GB/sample x 4 TTA samples
 FRAME_POINT_NUM = 160000         # config/StreamMOS.py:44 (Val.frame_point_num)
 
@@ -236,6 +238,11 @@ def main():
             "path_roofline": {"bound": "hbm", "achieved": round(value / world * ALG_GB_PER_SCAN, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(value / world * ALG_GB_PER_SCAN / HBM_PEAK_GBS, 4),
                               "note": "scans/s/GPU x 11.2 GB algorithmic bytes per scan (SURVEY.md 8d)"},
+            "path_compute_roofline": {"bound": "mfma", "achieved": round(value / world * ALG_TFLOP_PER_SCAN, 1),
+                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(value / world * ALG_TFLOP_PER_SCAN / FP32_PEAK_TFLOPS, 4),
+                                      "note": "the path computes in fp32 like the reference: 0.53 TFLOP/scan against the fp32 "
+                                              "MFMA/vector peak is the ceiling that binds first (296 scans/s), not HBM"},
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if world == 1:
