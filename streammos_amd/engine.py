@@ -104,6 +104,12 @@ class InferenceEngine:
         self.post2 = _fold(m[3].weight, None, m[4])
         p = net.pred_layer.pred_layer[0]
         self.pred = (p.weight.detach().contiguous(), p.bias.detach().contiguous())
+        self.refine = None                  # stage-2 model (models/StreamMOS_seg.py:21-30): a second point head
+        if hasattr(net, "refine"):
+            rm = net.refine.bf_point_post.merge_layer
+            rp = net.refine.bf_pred_layer.pred_layer[0]
+            self.refine = (_fold(rm[0].weight, None, rm[1]), _fold(rm[3].weight, None, rm[4]),
+                           (rp.weight.detach().contiguous(), rp.bias.detach().contiguous()))
         self.sums_ws = torch.zeros(4096, dtype=torch.float32, device=self.device)
         self.gate_ws = torch.zeros(65 * 4096, dtype=torch.float32, device=self.device)
         if layout == "cl":
@@ -185,6 +191,21 @@ class InferenceEngine:
             return torch._addmm_activation(wb[1], x, w.t(), use_gelu=False)
         except (RuntimeError, AttributeError):
             return torch.relu_(torch.addmm(wb[1], x, w.t()))
+
+    def _point_heads(self, fuse, aux, k, x2):
+        """CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3 (and the stage-2 refine head)."""
+        bs, n = fuse.shape[0], fuse.shape[1]
+        rows = fuse.view(bs * n, -1)
+
+        def head(l1, l2, pr):
+            z = self._linear_relu(self._linear_relu(rows, l1), l2)
+            out = torch.addmm(pr[1], z, pr[0].view(pr[0].shape[0], -1).t())
+            return out.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
+
+        pred = head(self.post1, self.post2, self.pred)
+        if self.refine is not None:
+            return pred, head(*self.refine), aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
 
     def _run_stage(self, x, blocks, out=None):
         for i, p in enumerate(blocks):
@@ -341,11 +362,7 @@ class InferenceEngine:
         aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
         k = self.aux[2]
         ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
-        z = self._linear_relu(fuse.view(bs * n, -1), self.post1)
-        z = self._linear_relu(z, self.post2)
-        pred = torch.addmm(self.pred[1], z, self.pred[0].view(self.pred[0].shape[0], -1).t())
-        pred = pred.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
-        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+        return self._point_heads(fuse, aux, k, x2)
 
     def _encode(self, point_feat, pcds_coord, pcds_sphere_coord):
         """Everything that does NOT depend on the previous frame: point MLP + input scatter, the three BEV stages
@@ -396,9 +413,4 @@ class InferenceEngine:
         k = self.aux[2]
 
         ops.gather_scatter(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
-        # CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3
-        z = self._linear_relu(fuse.view(bs * n, -1), self.post1)
-        z = self._linear_relu(z, self.post2)
-        pred = torch.addmm(self.pred[1], z, self.pred[0].view(self.pred[0].shape[0], -1).t())
-        pred = pred.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
-        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+        return self._point_heads(fuse, aux, k, x2)

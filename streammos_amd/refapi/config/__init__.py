@@ -1,2 +1,2 @@
 __smos_refapi__ = True
-from . import StreamMOS  # noqa: E402,F401
+from . import StreamMOS, StreamMOS_seg  # noqa: E402,F401

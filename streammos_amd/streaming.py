@@ -141,7 +141,7 @@ class StreamRunner:
                 # eager warm-up on a side stream: MIOpen algorithm search, lazy engine build, allocator pools
                 mem = None
                 for _ in range(2):
-                    mem = self.model.infer(batch, 0, None)[4]
+                    mem = self.model.infer(batch, 0, None)[-1]
                 g_mem = mem.clone()
                 for _ in range(2):
                     self.model.infer(batch, 1, g_mem)
@@ -151,7 +151,8 @@ class StreamRunner:
             for first in (True, False):
                 g = torch.cuda.CUDAGraph()
                 with torch.no_grad(), torch.cuda.graph(g):
-                    pred, _, _, _, mem = self.model.infer(batch, 0 if first else 1, None if first else g_mem)
+                    res = self.model.infer(batch, 0 if first else 1, None if first else g_mem)
+                    pred, mem = res[0], res[-1]
                     g_mem.copy_(mem)
                 graphs[first] = (g, pred)
             self._groups.append({"in": g_in, "mem": g_mem, "graphs": graphs, "slice": sl,
@@ -231,33 +232,42 @@ class StreamRunner:
                     t.record_stream(main)
                     t.record_stream(self._side)
             self._pre_enc = (next_dev, nxt)
-        pred_cls, _, _, _, self.memory = eng.decode(enc, self.memory if self.frame > 0 else None)
-        return pred_cls
+        return eng.decode(enc, self.memory if self.frame > 0 else None)
 
     @torch.no_grad()
     def step(self, dev, pose=None, next_dev=None):
         """One scan.  Returns dict(pred_cls, labels (N_pad,) uint8, raw_labels (n_raw,) uint8,
         voted = [(frame_id, int32 LUT labels)]).  next_dev: the following frame's inputs (pipeline mode)."""
+        bf_labels = None
         if self.use_graph:
             if self._graphs is None or self._g_shape != tuple(dev["pcds_xyzi"].shape):
                 self._capture(dev)
             pred_cls = self._replay(dev)        # static buffer: valid until the next step()
             labels = ops.tta_argmax(pred_cls)
             self.memory = [grp["mem"] for grp in self._groups]
-        elif self.pipeline:
-            pred_cls = self._pipelined(dev, next_dev)
-            labels = ops.tta_argmax(pred_cls)
         else:
-            batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
-            pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
+            if self.pipeline:
+                res = self._pipelined(dev, next_dev)
+            else:
+                batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+                res = self.model.infer(batch, self.frame, self.memory)
+            pred_cls, self.memory = res[0], res[-1]          # 5-tuple (stage 1) or 6-tuple (StreamMOS_seg)
             labels = ops.tta_argmax(pred_cls)
+            if len(res) == 6:
+                bf_labels = ops.tta_argmax(res[1])            # val_StreamMOS_seg.py:101-103
         out = {"pred_cls": pred_cls, "labels": labels, "voted": []}
+        if bf_labels is not None:
+            out["bf_pred_cls"], out["bf_labels"] = res[1], bf_labels
         raw = None
         if "prefix" in dev:                                                       # device-preprocessed sample
             raw = self._pre.unpad_labels(labels, dev)
         elif "valid_index" in dev:
             raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
             raw.index_copy_(0, dev["valid_index"], labels[:dev["n_valid"]])      # val_StreamMOS.py:112-118
+        if bf_labels is not None and "valid_index" in dev:       # the `_bf` prediction file of val_StreamMOS_seg.py:128-131,141
+            bf_raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
+            bf_raw.index_copy_(0, dev["valid_index"], bf_labels[:dev["n_valid"]])
+            out["bf_raw_labels"] = bf_raw
         if raw is not None:
             out["raw_labels"] = raw
             if self.voter is not None and "raw_scan" in dev:
@@ -289,7 +299,8 @@ class MultiStreamRunner:
     @torch.no_grad()
     def step(self, batched, poses):
         batch = {k: batched[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
-        pred_cls, _, _, _, self.memory = self.model.infer(batch, self.frame, self.memory)
+        res = self.model.infer(batch, self.frame, self.memory)
+        pred_cls, self.memory = res[0], res[-1]
         v = pred_cls.shape[0] // self.n
         outs = []
         for s, meta in enumerate(batched["streams"]):

@@ -160,6 +160,30 @@ def gen_e2e(ns, out):
         out["e2e_f%d_aux_sub" % i] = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].contiguous().numpy()
 
 
+def gen_seg(ns, out):
+    """Stage-2 model (models/StreamMOS_seg.py): state-dict layout and two chained frames incl. the refine head."""
+    import contextlib
+    import io
+    import json
+    import models.StreamMOS_seg as seg
+    import config.StreamMOS_seg as seg_cfg
+    from streammos_amd import synth
+    model = seg.AttNet(seg_cfg.get_config()[2]).eval()
+    layout_path = os.path.join(HERE, "state_dict_layout.json")
+    layout = json.load(open(layout_path))
+    layout["stage2_seg"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    json.dump(layout, open(layout_path, "w"), indent=0)
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    memory = None
+    for i, batch in enumerate(cases.e2e_frames(2)):
+        tb = {k: torch.from_numpy(v).unsqueeze(0) for k, v in batch.items()}
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):     # the reference prints the input shape
+            pred, bf, a0, a1, a2, memory = model.infer(tb, i, memory)
+        out["seg_f%d_in_sha" % i] = np.array(sha(batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"]))
+        out["seg_f%d_pred" % i] = pred.numpy()
+        out["seg_f%d_bf_pred" % i] = bf.numpy()
+
+
 def gen_losses(ns, out):
     """Training losses (row f2): the reference's CE_OHEM (utils/criterion.py:10-28) and lovasz_softmax
     (utils/lovasz_losses.py:147-222) on seeded logits, with the gradient of ce + 3 * lovasz."""
@@ -181,7 +205,7 @@ def main():
     for name, fn, needs_ns in (("ops_voxel_maxpool", gen_voxel_maxpool, True), ("ops_bilinear", gen_bilinear, True),
                                ("ops_msda", gen_msda, True), ("ops_voting", gen_voting, True),
                                ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True),
-                               ("losses", gen_losses, True)):
+                               ("losses", gen_losses, True), ("seg", gen_seg, True)):
         out = {}
         fn(ns, out) if needs_ns else fn(out)
         path = os.path.join(HERE, name + ".npz")

@@ -319,3 +319,32 @@ def test_pipelined_runner_equals_plain_runner(model):
         assert torch.equal(p0, p1) or (p0 - p1).abs().max().item() <= 1e-6 * p0.abs().max().item()
         assert torch.equal(r0, r1)
         assert [f for f, _ in v0] == [f for f, _ in v1] and all(torch.equal(a[1], b[1]) for a, b in zip(v0, v1))
+
+
+def test_seg_variant_engine_matches_reference_golden(golden):
+    """Stage-2 model (refine head) on the GPU engine: both point heads against the reference's outputs, two chained frames,
+    and through StreamRunner (which also emits the `_bf` labels of val_StreamMOS_seg.py)."""
+    from streammos_amd.refapi.config import StreamMOS_seg as seg_cfg
+    from streammos_amd.refapi.models import StreamMOS_seg
+    g = golden("seg")
+    m = StreamMOS_seg.AttNet(seg_cfg.get_config()[2])
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict()), strict=True)
+    m = m.to(DEV).eval()
+    memory = None
+    with torch.no_grad():
+        for i, batch in enumerate(cases.e2e_frames(2)):
+            check_inputs(g, "seg_f%d_in_sha" % i, batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"])
+            tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+            pred, bf, a0, a1, a2, memory = m.infer(tb, i, memory)
+            for got, key in ((pred, "seg_f%d_pred" % i), (bf, "seg_f%d_bf_pred" % i)):
+                ref = g[key]
+                assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+                assert (got.cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.995
+    spec = preprocess.VoxelSpec()
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(4)]
+    poses = [synth.synthetic_pose(k) for k in range(4)]
+    runner = streaming.StreamRunner(m, DEV, vote=False, pipeline=True)
+    idx = preprocess.window_indices(0, 4, 3)
+    sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+    out = runner.step(runner.upload(sample, scans[0]), poses[0])
+    assert out["bf_raw_labels"].shape == out["raw_labels"].shape and int(out["bf_raw_labels"].max()) <= 2

@@ -286,3 +286,27 @@ if rank == 0:
                       "changed": bool((w - before).abs().max() > 0)}))
 dist.destroy_process_group()
 """
+
+
+def test_seg_variant_layout_and_cpu_graph_match_reference(golden, monkeypatch):
+    """models.StreamMOS_seg.AttNet (stage 2, + refine head): 488-tensor layout and the module graph on CPU against the
+    reference's outputs (GPU-only sampler swapped for the debug torch formulation)."""
+    from streammos_amd.refapi import MultiScaleDeformableAttention as msda
+    from streammos_amd.refapi.config import StreamMOS_seg as cfg
+    from streammos_amd.refapi.deformattn.functions import ms_deform_attn_core_pytorch
+    from streammos_amd.refapi.models import StreamMOS_seg
+    monkeypatch.setattr(msda, "ms_deform_attn_forward",
+                        lambda v, s, l, loc, w, step: ms_deform_attn_core_pytorch(v, s, loc, w))
+    m = StreamMOS_seg.AttNet(cfg.get_config()[2]).eval()
+    layout = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))["stage2_seg"]
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()] == layout
+    assert len(layout) == 488 and cfg.get_config()[2].prefix == "StreamMOS_seg.AttNet"
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict()), strict=True)
+    g = golden("seg")
+    batch = next(iter(cases.e2e_frames(1)))
+    check_inputs(g, "seg_f0_in_sha", batch["pcds_xyzi"], batch["pcds_coord"], batch["pcds_sphere_coord"])
+    with torch.no_grad():
+        out = m.infer({k: torch.from_numpy(v).unsqueeze(0) for k, v in batch.items()}, 0)
+    assert len(out) == 6
+    for got, key in ((out[0], "seg_f0_pred"), (out[1], "seg_f0_bf_pred")):
+        assert np.abs(got.numpy() - g[key]).max() <= 1e-4 * np.abs(g[key]).max()
