@@ -18,9 +18,14 @@ import torch
 from . import kitti, preprocess, streaming, synth
 
 
-def load_model(checkpoint=None, device="cuda:0"):
-    from .refapi.config import StreamMOS as cfg
-    from .refapi.models import StreamMOS
+def load_model(checkpoint=None, device="cuda:0", seg=False):
+    """seg=True: the stage-2 model (models/StreamMOS_seg.py) whose refine head also yields the `_bf` labels."""
+    if seg:
+        from .refapi.config import StreamMOS_seg as cfg
+        from .refapi.models import StreamMOS_seg as StreamMOS
+    else:
+        from .refapi.config import StreamMOS as cfg
+        from .refapi.models import StreamMOS
     model = StreamMOS.AttNet(cfg.get_config()[2])
     if checkpoint:
         state = torch.load(checkpoint, map_location="cpu", weights_only=True)
@@ -65,6 +70,9 @@ def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_poin
         out = runner.step(runner.upload(sample, scan(i)), poses[i])
         raw = out["raw_labels"].cpu().numpy()
         kitti.write_prediction(os.path.join(out_dir, "predictions", files[i][:-4] + ".label"), labels_012=raw)
+        if "bf_raw_labels" in out:          # val_StreamMOS_seg.py:141: raw 0/1/2 words, no LUT
+            kitti.write_prediction(os.path.join(out_dir, "predictions_bf", files[i][:-4] + ".label"),
+                                   lut_labels=out["bf_raw_labels"].cpu().numpy())
         if has_gt:
             m_raw.add(gt(i), raw)
         emit_refined(out["voted"])
@@ -85,13 +93,14 @@ def main():
     ap.add_argument("--checkpoint", default=None)
     ap.add_argument("--device", default=None)
     ap.add_argument("--no-vote", action="store_true")
+    ap.add_argument("--seg", action="store_true", help="stage-2 model StreamMOS_seg (488-tensor checkpoint)")
     ap.add_argument("--limit", type=int, default=None)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = args.device or "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     lengths = {d: len(os.listdir(os.path.join(d, "velodyne"))) for d in args.seq_dir}
     mine = streaming.shard_sequences(lengths, world)[rank]
-    model = load_model(args.checkpoint, device)
+    model = load_model(args.checkpoint, device, seg=args.seg)
     for d in mine:
         out = os.path.join(args.out_dir, os.path.basename(os.path.normpath(d))) if len(args.seq_dir) > 1 else args.out_dir
         print(json.dumps(run_sequence(model, d, out, device, vote=not args.no_vote, limit=args.limit)), flush=True)
