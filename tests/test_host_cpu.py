@@ -251,7 +251,7 @@ class _Fn:
     @staticmethod
     def apply(value, shapes, lsi, loc, attn, step):
         return fn.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
-import streammos_amd.refapi.deformattn.modules.ms_deform_attn as mod
+import streammos_amd.refapi.deformattn._msda as mod
 mod.MSDeformAttnFunction = _Fn
 
 dist.init_process_group("gloo")
