@@ -110,8 +110,6 @@ class InferenceEngine:
             rp = net.refine.bf_pred_layer.pred_layer[0]
             self.refine = (_fold(rm[0].weight, None, rm[1]), _fold(rm[3].weight, None, rm[4]),
                            (rp.weight.detach().contiguous(), rp.bias.detach().contiguous()))
-        self.sums_ws = torch.zeros(4096, dtype=torch.float32, device=self.device)
-        self.gate_ws = torch.zeros(65 * 4096, dtype=torch.float32, device=self.device)
         if layout == "cl":
             for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
                 for p in blocks:
@@ -177,9 +175,8 @@ class InferenceEngine:
         y2 = F.conv2d(y, p.w2, None, 1, 1)
         dst = out if out is not None else y2
         if p.att:
-            if y2.shape[0] * y2.shape[1] > self.sums_ws.numel():
-                self.sums_ws = torch.zeros(y2.shape[0] * y2.shape[1], dtype=torch.float32, device=y2.device)
-            return ops.channel_gate_residual(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.sums_ws, out=dst)
+            return ops.channel_gate_residual(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self._block_ws(p, y2.shape[0] * y2.shape[1]),
+                                             out=dst)
         return ops.bias_act(y2, p.b2, RELU, out=dst, residual=x)
 
     @staticmethod
@@ -206,6 +203,14 @@ class InferenceEngine:
         if self.refine is not None:
             return pred, head(*self.refine), aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
         return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+
+    def _block_ws(self, p, n_floats):
+        """Scratch of one channel-attention block.  Every block owns its buffer: blocks of different pipeline stages run
+        concurrently on different HIP streams, a shared scratch would be a data race."""
+        ws = getattr(p, "ws", None)
+        if ws is None or ws.numel() < n_floats:
+            ws = p.ws = torch.zeros(n_floats, dtype=torch.float32, device=self.device)
+        return ws
 
     def _run_stage(self, x, blocks, out=None):
         for i, p in enumerate(blocks):
@@ -281,10 +286,22 @@ class InferenceEngine:
             return self._encode(point_feat, pcds_coord, pcds_sphere_coord)
 
     def decode(self, enc, memory=None):
+        return self.decode_heads(enc, self.decode_memory(enc, memory))
+
+    def decode_memory(self, enc, memory=None):
+        """The only part that is serial across frames: third BEV stage + deformable-attention fusion with the previous
+        frame's memory.  Returns the new memory (= the fused 1/8-resolution map)."""
         with torch.no_grad(), self._conv_flags():
             if self.layout == "cl":
-                return self._decode_cl(enc, memory)
-            return self._decode(enc, memory)
+                return self._temporal_fusion(self._stage_cl(enc["x1cat"], self.res2), memory, channels_last=True)
+            return self._temporal_fusion(enc["x2"], memory)
+
+    def decode_heads(self, enc, x2):
+        """Decoder convs, aux heads, bev->point gather and the point heads; nothing here feeds the next frame."""
+        with torch.no_grad(), self._conv_flags():
+            if self.layout == "cl":
+                return self._decode_cl(enc, x2)
+            return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
     def _block_cl(self, x, p, out=None):
@@ -305,9 +322,7 @@ class InferenceEngine:
         dst = out if out is not None else y2
         if p.att:
             need = (y2.shape[2] * y2.shape[3] // 512 + 2) * y2.shape[0] * y2.shape[1]
-            if need > self.gate_ws.numel():
-                self.gate_ws = torch.zeros(need, dtype=torch.float32, device=y2.device)
-            return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self.gate_ws, out=dst)
+            return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self._block_ws(p, need), out=dst)
         return ops.bias_act_cl(y2, p.b2, RELU, out=dst, residual=x)
 
     def _stage_cl(self, x, blocks, out=None):
@@ -350,10 +365,8 @@ class InferenceEngine:
         # pipeline stages (encode ~4.0 ms, decode ~4.0 ms of kernel time) so both HIP streams stay busy
         return {"x0cat": x0cat, "x1cat": x1cat, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
 
-    def _decode_cl(self, enc, memory=None):
+    def _decode_cl(self, enc, x2):
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
-        bs, n = fuse.shape[0], fuse.shape[1]
-        x2 = self._temporal_fusion(self._stage_cl(x1cat, self.res2), memory, channels_last=True)
         dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
         y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
         ops.bias_act_cl(y, self.conv_1[1], LEAKY, out=y)
@@ -397,12 +410,9 @@ class InferenceEngine:
         x2 = self._run_stage(x1cat, self.res2)
         return {"x0cat": x0cat, "x1cat": x1cat, "x2": x2, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
 
-    def _decode(self, enc, memory=None):
-        """Temporal fusion with the memory of the previous frame, decoder, point head (multi_view_encoder.py:426-456,
-        models/StreamMOS.py:105-113)."""
+    def _decode(self, enc, x2):
+        """Decoder and point heads of the NCHW engine (multi_view_encoder.py:441-456, models/StreamMOS.py:105-113)."""
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
-        bs, n = fuse.shape[0], fuse.shape[1]
-        x2 = self._temporal_fusion(enc["x2"], memory)
 
         dec_in = ops.upsample_concat([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
         y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
