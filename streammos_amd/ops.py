@@ -22,10 +22,13 @@ def _require_cuda(name, *tensors):
 
 
 def _flag(device):
-    ws = _flag_ws.get(device)
+    """4-byte "saw a negative feature" scratch of the scatter; one per (device, stream) so that launches on different
+    HIP streams never share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _flag_ws.get(key)
     if ws is None:
         ws = torch.zeros(4, dtype=torch.int32, device=device)
-        _flag_ws[device] = ws
+        _flag_ws[key] = ws
     return ws
 
 
