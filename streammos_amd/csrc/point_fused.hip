@@ -142,6 +142,7 @@ __global__ __launch_bounds__(kBlock, 4) void pointnet_scatter(PnsArgs a) {
   }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // bilinear gather (NCHW or any-stride grid) -> [optional point rows] -> [optional max scatter, channels-last]
 // ---------------------------------------------------------------------------------------------
