@@ -1,9 +1,9 @@
 // Fused point-side kernels of the inference engine (gfx950).
 //
-//   pointnet_scatter : per-point MLP 7 -> 64 -> 64 (BatchNorm folded, ReLU) computed in registers and
-//                      max-scattered straight into the channels-last BEV grid -- the (BS*T, 64, N) feature
-//                      tensor of the reference (491 MB written by point_pre and read back by VoxelMaxPool,
-//                      models/StreamMOS.py:101-102) never exists.
+//   pointnet_scatter : per-point MLP 7 -> 64 -> 64 (BatchNorm folded, ReLU) on the matrix cores (exact-f32 MFMA, both
+//                      layers chained in registers) and max-scattered straight into the channels-last BEV grid
+//                      -- the (BS*T, 64, N) feature tensor of the reference (491 MB written by point_pre and
+//                      read back by VoxelMaxPool, models/StreamMOS.py:101-102) never exists.
 //   gather_scatter   : grid -> point bilinear gather fused with the point -> grid max scatter of the other
 //                      view (B2P -> P2R and R2P -> P2B, networks/multi_view_encoder.py:395-404,410-419);
 //                      optionally also emits the gathered point features (x1_point / the final
@@ -20,12 +20,6 @@
 #include "smos_common.h"
 
 namespace smos {
-
-// Weights are wave-uniform: reading them through the constant address space makes hipcc emit scalar
-// loads (s_load_dwordx8/16 into SGPRs, consumed directly as the scalar operand of v_fmac) instead of
-// per-lane vector loads that would occupy the VGPR file.
-typedef const float __attribute__((address_space(4))) cfloat;
-__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)(uintptr_t)p; }
 
 constexpr int kTileP = 64;   // points per wave tile
 constexpr int kTileC = 32;   // channels per round
@@ -83,65 +77,182 @@ struct PnsArgs {
   int S, T, N, K, H, W, tiles_per_sample;
 };
 
-__global__ __launch_bounds__(kBlock, 4) void pointnet_scatter(PnsArgs a) {
-  __shared__ float lds_tile[kBlock / kWave][kTileP * kPitch];
-  __shared__ int lds_cell[kBlock / kWave][kTileP];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t n_tiles = (int64_t)a.S * a.tiles_per_sample;
-  // every wave of a block runs the same number of iterations (block-level barriers inside)
-  for (int64_t tile0 = (int64_t)blockIdx.x * (kBlock / kWave); tile0 < n_tiles; tile0 += (int64_t)gridDim.x * (kBlock / kWave)) {
-    const int64_t tile = tile0 + wave;
-    const bool live = tile < n_tiles;
-    const int s = live ? (int)(tile / a.tiles_per_sample) : 0;
-    const int n0 = live ? (int)(tile - (int64_t)s * a.tiles_per_sample) * kTileP : 0;
-    const int n = n0 + lane;
-    const bool has = live && n < a.N;
-    const int b = s / a.T, t = s - b * a.T;
+// Matrix-core formulation.  Both layers are computed TRANSPOSED, C = W * X with the output channel on the MFMA row
+// and the point on the MFMA column (v_mfma_f32_32x32x2_f32: exact f32, the fp32 vector rate):
+//   * the weights are the A operand: one VGPR per (32-channel block, k-step), 8 + 64 registers loaded ONCE per wave and
+//     kept for the whole persistent loop -- no per-tile weight traffic at all (the scalar-load version re-streams 18 KB
+//     per tile through a 16 KB scalar cache that it thrashes; measured: 0.40 ms, 0.26 ms with half the weights);
+//   * the points are the B operand: lane l holds feature 2s + (l >> 5) of point (l & 31), read straight from the
+//     channel-major input; feature 7 is the constant 1 that carries the folded layer-1 bias;
+//   * a 32x32 result tile has its point on the lane and its channels in the 16 accumulator registers, which IS the B
+//     operand layout of the next layer: register r of lane half h is channel 8(r>>2) + 4h + (r&3), so layer 2 walks the
+//     hidden channels in that order (its A operand is loaded with the same permutation) and takes relu(C1) with no lane
+//     movement and no LDS.
+// The 32-point x 64-channel output tile goes through LDS once (point-major rows, pitch 68) and leaves with lane =
+// channel: every store / atomic is one contiguous 256-byte row.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kNt = 32;        // points per MFMA column tile
+constexpr int kPitchM = 68;    // floats per LDS row (64 channels + 4: conflict-free 128-bit row writes)
 
-    float x[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) x[j] = has ? a.xyzi[((int64_t)s * 7 + j) * a.N + n] : 0.0f;
-    lds_cell[wave][lane] = has ? cell_2d(a.coord + ((int64_t)s * a.N + n) * a.K, 1.0f, 1.0f, a.H, a.W) : -1;
-
-    cfloat* w1 = as_const(a.w1);
-    cfloat* b1 = as_const(a.b1);
-    cfloat* w2 = as_const(a.w2);
-    cfloat* b2 = as_const(a.b2);
-    float h[64];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      float acc = b1[k];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) acc = fmaf(w1[k * 7 + j], x[j], acc);
-      h[k] = fmaxf(acc, 0.0f);
-    }
-    const int n_valid = live ? min(kTileP, a.N - n0) : 0;
-    float* grid_base = a.bev + (int64_t)b * a.bev_sb;
-    float* pts_base = (a.pts_out && t == 0 && live) ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n : nullptr;
-#pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
-      float* row = &lds_tile[wave][lane * kPitch];
-#pragma unroll
-      for (int j4 = 0; j4 < kTileC; j4 += 4) {
-        float y[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = r * kTileC + j4 + u;
-          float acc = b2[j];
-#pragma unroll
-          for (int k = 0; k < 64; ++k) acc = fmaf(w2[j * 64 + k], h[k], acc);
-          y[u] = fmaxf(acc, 0.0f);
-        }
-        *reinterpret_cast<float4*>(row + j4) = make_float4(y[0], y[1], y[2], y[3]);
-      }
-      __syncthreads();
-      if (live) rows_phase(lds_tile[wave], lds_cell[wave], lane, grid_base, (int64_t)a.T * 64, t * 64 + r * kTileC, pts_base,
-                           a.po_n, n_valid);
-      __syncthreads();
-    }
-  }
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
+  __shared__ float lds_tile[kBlock / kWave][kNt * kPitchM];
+  __shared__ float lds_b2[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = lane & 31, hh = lane >> 5;
+  float w1a[2][4], w2a[2][32];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = 2 * s + hh;
+      w1a[mt][s] = k < 7 ? a.w1[(mt * 32 + col) * 7 + k] : a.b1[mt * 32 + col];
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int r = s & 15;
+      const int k = (s >> 4) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      w2a[mt][s] = a.w2[(mt * 32 + col) * 64 + k];
+    }
+  }
+  if (threadIdx.x < 64) lds_b2[threadIdx.x] = a.b2[threadIdx.x];
+  __syncthreads();
+
+  // tile bookkeeping is wave-uniform 32-bit arithmetic (the host checks that the tile count fits): it stays on the
+  // scalar unit, which matters because VALU instructions issue through the same port as the MFMAs
+  const int nt_per_sample = (a.N + kNt - 1) / kNt;
+  const int n_nt = a.S * nt_per_sample;
+  float* tile = lds_tile[wave];
+  const int nt_step = (int)gridDim.x * (kBlock / kWave);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // inputs of one column tile: 4 features per lane + the two grid coordinates of the lane's point
+  struct TileIn {
+    float x[4], cy, cx;
+  };
+  auto fetch = [&](int nt, TileIn& in) {
+    const bool live = nt < n_nt;
+    const int s = live ? nt / nt_per_sample : 0;
+    const int n0 = live ? (nt - s * nt_per_sample) * kNt : 0;
+    const bool has = live && n0 + col < a.N;
+    const float* xs = a.xyzi + (int64_t)s * 7 * a.N + n0;          // wave-uniform base, per-lane offset below
+    const int lane_off = hh * a.N + col;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = 2 * q + hh;
+      in.x[q] = f < 7 ? (has ? xs[(int64_t)2 * q * a.N + lane_off] : 0.0f) : 1.0f;
+    }
+    const float* cr = a.coord + ((int64_t)s * a.N + n0) * a.K;
+    in.cy = has ? cr[col * a.K] : -1.0f;   // -1 is outside the half-open test of cell_2d
+    in.cx = has ? cr[col * a.K + 1] : -1.0f;
+  };
+
+  auto cell_of = [&](const TileIn& in) {
+    const float yx[2] = {in.cy, in.cx};
+    return cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
+  };
+  int nt = (int)blockIdx.x * (kBlock / kWave) + wave_u;
+  TileIn cur;
+  fetch(nt, cur);
+  int cell = cell_of(cur);
+  for (; nt < n_nt; nt += nt_step) {
+    // Software pipeline: the next tile's loads are issued here and waited for after this tile's matrix phase, BEFORE
+    // this tile's stores and atomics are issued.  The vector-memory counter of gfx9 retires in order and the number of
+    // atomics is data dependent, so a wait placed after them would be a wait for all of them (vmcnt(0)).
+    TileIn nxt;
+    fetch(nt + nt_step, nxt);
+    const int s = nt / nt_per_sample;
+    const int n0 = (nt - s * nt_per_sample) * kNt;
+    const int b = s / a.T, t = s - b * a.T;
+    float xk[4] = {cur.x[0], cur.x[1], cur.x[2], cur.x[3]};
+    // the shuffle is its own statement: inside the short-circuit expression it would run with lane 31 masked off, and
+    // a lane that reads a masked-off lane gets 0 -- indistinguishable from cell 0
+    const int cell_after = __shfl_down(cell, 1);
+    const uint32_t tails = (uint32_t)__ballot(hh == 0 && (col == kNt - 1 || cell != cell_after));
+
+    f32x16 c1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c1[mt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) c1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[mt][q], xk[q], c1[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c1[mt][r] = fmaxf(c1[mt][r], 0.0f);
+
+    f32x16 c2[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bias = *reinterpret_cast<const float4*>(&lds_b2[mt * 32 + 8 * g + 4 * hh]);
+        c2[mt][4 * g + 0] = bias.x; c2[mt][4 * g + 1] = bias.y; c2[mt][4 * g + 2] = bias.z; c2[mt][4 * g + 3] = bias.w;
+      }
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        c2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[mt][q], c1[q >> 4][q & 15], c2[mt], 0, 0, 0);
+
+    float* row = tile + col * kPitchM + 4 * hh;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(row + mt * 32 + 8 * g) =
+            make_float4(fmaxf(c2[mt][4 * g], 0.0f), fmaxf(c2[mt][4 * g + 1], 0.0f), fmaxf(c2[mt][4 * g + 2], 0.0f),
+                        fmaxf(c2[mt][4 * g + 3], 0.0f));
+    wave_sync();
+
+    // lane = channel: 32 points, each one 256-byte row.  All 32 LDS reads are issued before the first use, the point
+    // rows leave first, then same-cell runs are reduced in registers and flushed with one row atomic per run; the run
+    // ends are a wave-uniform bit mask, so the control flow is scalar.
+    const int n_valid = min(kNt, a.N - n0);
+    const unsigned ulane = lane;   // zero-extended lane offset: lets the stores use the scalar-base addressing form
+    float v[kNt];
+#pragma unroll
+    for (int i = 0; i < kNt; ++i) v[i] = tile[i * kPitchM + lane];
+    // the prefetch is waited for here (tied to the last LDS read so that the scheduler cannot hoist the wait)
+    asm volatile("" : "+v"(nxt.x[0]), "+v"(nxt.x[1]), "+v"(nxt.x[2]), "+v"(nxt.x[3]), "+v"(nxt.cy), "+v"(nxt.cx), "+v"(v[kNt - 1]));
+    const int cell_next = cell_of(nxt);
+    if (a.pts_out && t == 0) {
+      float* prow = a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n;   // wave-uniform
+      if (n_valid == kNt) {
+#pragma unroll
+        for (int i = 0; i < kNt; ++i) (prow + (int64_t)i * a.po_n)[ulane] = v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < kNt; ++i)
+          if (i < n_valid) (prow + (int64_t)i * a.po_n)[ulane] = v[i];
+      }
+    }
+    float* gsample = a.bev + (int64_t)b * a.bev_sb + t * 64;   // wave-uniform
+    const int64_t cell_pitch = (int64_t)a.T * 64;
+    float best = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNt; ++i) {
+      best = fmaxf(best, v[i]);
+      if ((tails >> i) & 1) {
+        const int ci = __builtin_amdgcn_readlane(cell, i);
+        if (ci >= 0 && best > 0.0f)
+          atomicMax(reinterpret_cast<int*>(gsample + (int64_t)ci * cell_pitch) + ulane, __float_as_int(best));
+        best = 0.0f;
+      }
+    }
+    wave_sync();
+    cur = nxt;
+    cell = cell_next;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // bilinear gather (NCHW or any-stride grid) -> [optional point rows] -> [optional max scatter, channels-last]
@@ -269,10 +380,23 @@ extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int3
   a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.pts_out = pts_out;
   a.bev_sb = H * W * T * 64; a.po_b = po_b; a.po_n = po_n;
   a.S = (int)(B * T); a.T = (int)T; a.N = (int)N; a.K = K; a.H = (int)H; a.W = (int)W;
-  a.tiles_per_sample = (int)((N + kTileP - 1) / kTileP);
-  const int64_t tiles = (int64_t)a.S * a.tiles_per_sample;
-  const int64_t blocks = (tiles + 3) / 4;
-  hipLaunchKernelGGL(pointnet_scatter, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(kBlock), 0,
+  a.tiles_per_sample = (int)((N + kNt - 1) / kNt);
+  // persistent waves: exactly as many blocks as are resident at once
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pointnet_scatter, kBlock, 0) != hipSuccess || per_cu < 1) {
+      set_error("pointnet_scatter: occupancy query failed");
+      return SMOS_ERR_LAUNCH;
+    }
+    resident = per_cu * prop.multiProcessorCount;
+  }
+  const int64_t n_nt = (int64_t)a.S * ((N + kNt - 1) / kNt);
+  SMOS_REQUIRE(n_nt < (1LL << 30), "pointnet_scatter: too many points for 32-bit tile indices");
+  const int64_t want = (n_nt + 3) / 4;
+  hipLaunchKernelGGL(pointnet_scatter, dim3((unsigned)(want < resident ? want : resident)), dim3(kBlock), 0,
                      (hipStream_t)stream, a);
   return check_launch("pointnet_scatter");
 }

@@ -269,6 +269,33 @@ def test_pointnet_scatter_against_unfused_ops(n):
     assert (rows[:, :, :64] == -7.0).all() and (rows[:, :, 128:] == -7.0).all()
 
 
+def test_pointnet_scatter_run_boundaries_at_cell_zero():
+    """Regression: cell 0 is a legal cell.  Run ends are found with a lane shuffle; evaluated under a partial exec
+    mask a lane reading a masked-off neighbour gets 0, which made a point of cell 0 at position 30 of a 32-point tile
+    merge into the following point's run (seen at full size only: one point in 1.9 M)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(29)
+    b, t, h, w, n = 1, 3, 32, 32, 32 * 40
+    xyzi = torch.randn((b, t, 7, n, 1), generator=gen).to(DEV)
+    coord = torch.cat((_model_like_coords(gen, b * t, n, h, w), torch.rand((b * t, n, 1), generator=gen)), -1)
+    for pos in (0, 1, 15, 29, 30, 31):                      # lone cell-0 points at several tile positions
+        coord[:, pos + 64 * (pos % 5)::32 * 7, 0] = 0.41
+        coord[:, pos + 64 * (pos % 5)::32 * 7, 1] = 0.19
+    coord[:, 32 * 20:32 * 22, :2] = 0.5                     # and a run of cell 0 spanning two tiles
+    coord = coord.view(b, t, n, 3, 1).to(DEV)
+    w1, b1 = (torch.randn((64, 7, 1, 1), generator=gen) * 0.4).to(DEV), torch.randn(64, generator=gen).to(DEV) * 0.1
+    w2, b2 = (torch.randn((64, 64, 1, 1), generator=gen) * 0.15).to(DEV), torch.randn(64, generator=gen).to(DEV) * 0.1
+    bev = torch.zeros((b, h, w, t * 64), device=DEV)
+    ops.pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev)
+    x = xyzi.view(b * t, 7, n, 1).double()
+    pts = F.relu(F.conv2d(F.relu(F.conv2d(x, w1.double(), b1.double())), w2.double(), b2.double())).float()
+    want = torch.zeros((b * t, 64, h, w), device=DEV)
+    ops.voxel_maxpool_fwd(pts, coord.view(b * t, n, 3)[:, :, :2].contiguous(), want, (h, w), (1.0, 1.0))
+    got = bev.permute(0, 3, 1, 2).reshape(b, t, 64, h, w).reshape(b * t, 64, h, w)
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert want[:, :, 0, 0].max().item() > 0
+
+
 @pytest.mark.parametrize("c,hw_g,hw_o,sg,ss", [(32, (64, 64), (8, 256), (0.5, 0.5), (0.5, 0.5)),
                                               (64, (16, 128), (32, 32), (0.25, 0.25), (0.25, 0.25))])
 def test_gather_scatter_against_unfused_ops(c, hw_g, hw_o, sg, ss):
