@@ -35,5 +35,7 @@ for name, cnt, cin, cout, hw, k, st, pad in layers:
     xc = x.contiguous(memory_format=torch.channels_last); wc = w.contiguous(memory_format=torch.channels_last)
     tc = timeit(lambda: F.conv2d(xc, wc, None, st, pad))
     tot_n += cnt * tn; tot_c += cnt * tc; tot_best += cnt * min(tn, tc)
-    print("%-24s x%2d  nchw %.3f  cl %.3f  %s" % (name, cnt, tn, tc, "<-- cl" if tc < 0.9 * tn else ""), flush=True)
+    ho, wo = (hw[0] + 2 * (pad if isinstance(pad, int) else pad[0]) - k[0]) // st + 1, (hw[1] + 2 * (pad if isinstance(pad, int) else pad[1]) - k[1]) // st + 1
+    gf = 2.0 * 4 * ho * wo * cout * cin * k[0] * k[1] / 1e9
+    print("%-24s x%2d  nchw %.3f  cl %.3f  %s  cl: %6.1f TF/s  layer total %.3f ms" % (name, cnt, tn, tc, "<-- cl" if tc < 0.9 * tn else "      ", gf / tc, cnt * tc), flush=True)
 print("total nchw %.3f  cl %.3f  best-per-layer %.3f ms" % (tot_n, tot_c, tot_best))
