@@ -234,3 +234,73 @@ def vote_frame(cur_points, cur_pred, hist_points, hist_pred):
     out = np.asarray(cur_pred).astype(np.int64).copy()
     out[ck] = new
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Instance-level voting (voxel_instance_voting.py:144-193, 195-272).  PARITY UNPINNED against the reference itself: the
+# script cannot be imported (np.bool, scipy.spatial.qhull, yaml.load without Loader, argparse at module level), so
+# this restatement follows its source text and calls the same third-party routines (scikit-learn DBSCAN, scipy
+# ConvexHull / Delaunay, unpinned in requirements.txt:3,9) that the reference calls.
+# ---------------------------------------------------------------------------------------------------
+def instance_box_corners(cluster_points):
+    """min_bounding_box_3d (:43-60): the axis-aligned box of the convex-hull vertices, i.e. of the points.  The
+    reference lets scipy raise on a degenerate (coplanar) cluster; here the box is taken from the points directly."""
+    from scipy.spatial import ConvexHull, QhullError
+    pts = np.array(cluster_points)
+    try:
+        pts = pts[ConvexHull(pts).vertices]
+    except QhullError:
+        pass
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    return np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                     [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]])
+
+
+def instance_in_hull(p, corners):
+    """in_hull (:62-76): Delaunay triangulation of the corners, find_simplex >= 0; a degenerate box contains nothing."""
+    from scipy.spatial import Delaunay, QhullError
+    try:
+        return Delaunay(corners).find_simplex(p) >= 0
+    except QhullError:
+        return np.zeros(p.shape[0], dtype=bool)
+
+
+def instance_cluster(cur_points, cur_pred, cur_bf, local_points, local_pred, eps=0.3, min_samples=5, min_points=30):
+    """cluster() (:144-193).  cur_points (n,>=3) float32 raw scan, cur_pred (n,) labels after the voxel vote, cur_bf
+    (n,) movable-object prediction (2 = foreground), local_points / local_pred: the cropped local map (history + current)
+    with its PRE-vote predictions.  Returns the (n,) labels with every kept cluster overwritten by its majority class."""
+    from sklearn.cluster import DBSCAN
+    out = np.asarray(cur_pred).copy()
+    fg = np.where(np.asarray(cur_bf) == 2)[0]
+    if len(fg) == 0:
+        return out
+    fpts = np.asarray(cur_points)[fg][:, :3]
+    lab = DBSCAN(eps=eps, min_samples=min_samples).fit_predict(fpts)
+    local_xyz = np.asarray(local_points)[:, :3]
+    local_pred = np.asarray(local_pred)
+    for c in np.unique(lab):
+        if c == -1:
+            continue
+        member = lab == c
+        if int(member.sum()) <= min_points:
+            continue
+        corners = instance_box_corners(fpts[member])
+        z_min = np.min(corners[:, -1])
+        corners[np.where(corners[:, -1] == z_min), -1] += 0.2          # :171-173, in the corners' float32
+        inside = instance_in_hull(local_xyz, corners)
+        pred_in = local_pred[inside]
+        static_num = int(np.sum(pred_in[pred_in == 1]))                  # :178  = count of 1s
+        dynamic_num = int(np.sum(pred_in[pred_in == 2]))                 # :179  = 2 x count of 2s (a SUM of labels)
+        out[fg[member]] = 2 if dynamic_num > static_num else 1
+    return out
+
+
+def instance_vote_frame(cur_points, cur_pred, cur_bf, hist_points, hist_pred):
+    """post_processing (:195-272) for one frame: the voxel vote of vote_frame, then cluster() on the result, with the
+    local map = cropped history (already pose-aligned) + cropped current scan and their pre-vote predictions."""
+    hk = vote_crop_mask(hist_points)
+    ck = vote_crop_mask(cur_points)
+    local_points = np.concatenate((np.asarray(hist_points)[hk], np.asarray(cur_points)[ck]), axis=0)
+    local_pred = np.concatenate((np.asarray(hist_pred)[hk], np.asarray(cur_pred)[ck]), axis=0).astype(np.int64)
+    voted = vote_frame(cur_points, cur_pred, hist_points, hist_pred)
+    return instance_cluster(cur_points, voted, cur_bf, local_points, local_pred)

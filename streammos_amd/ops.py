@@ -208,6 +208,47 @@ def vote_resolve(points, labels, table, lut=None, recip_quantize=False):
     return out
 
 
+def dbscan(points, eps, min_samples, max_sweeps=4096):
+    """sklearn.cluster.DBSCAN(eps, min_samples).fit_predict(points[:, :3]) on the device (voxel_instance_voting.py:150-153).
+    points [n, >=3] float32 rows.  Returns int32 [n]: the index of the cluster's lowest-index core point, -1 for noise
+    (rank the distinct values to get scikit-learn's 0,1,2.. numbering).  Synchronises the stream."""
+    _require_cuda("dbscan", points)
+    if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] < 3 or points.stride(1) != 1:
+        raise RuntimeError("dbscan: points must be float32 rows [n, >=3]")
+    n = points.shape[0]
+    labels = torch.empty(n, dtype=torch.int32, device=points.device)
+    if n == 0:
+        return labels
+    work = torch.empty(n + 1, dtype=torch.int32, device=points.device)
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        rc = lib.smos_dbscan(points.data_ptr(), n, points.stride(0), float(eps), int(min_samples), labels.data_ptr(),
+                             work.data_ptr(), int(max_sweeps), _stream(points))
+    _lib.check(rc, "smos_dbscan")
+    return labels
+
+
+def box_vote(points, labels, boxes, counts, pose_diff=None):
+    """counts [K,3] uint32/int32 (zero-filled by the caller) += per-box class counts of one frame's kept points
+    (voxel_instance_voting.py:170-179).  boxes [K,6] float32 (lo xyz, hi xyz), closed intervals."""
+    _require_cuda("box_vote", points, labels, boxes, counts)
+    if points.dtype != torch.float32 or labels.dtype != torch.uint8 or points.stride(1) != 1:
+        raise RuntimeError("box_vote: points must be float32 rows and labels uint8")
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.dim() != 2 or boxes.shape[1] != 6:
+        raise RuntimeError("box_vote: boxes must be a contiguous float32 [K, 6] tensor")
+    if counts.dtype not in (torch.int32, torch.uint32) or not counts.is_contiguous() or counts.numel() != boxes.shape[0] * 3:
+        raise RuntimeError("box_vote: counts must be a contiguous 32-bit [K, 3] tensor")
+    pose = None
+    if pose_diff is not None:
+        pose = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        rc = lib.smos_box_vote(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(), pose,
+                               boxes.data_ptr(), boxes.shape[0], counts.data_ptr(), _stream(points))
+    _lib.check(rc, "smos_box_vote")
+    return counts
+
+
 # ---------------------------------------------------------------------------------------------
 # fused encoder epilogues (inference engine)
 # ---------------------------------------------------------------------------------------------

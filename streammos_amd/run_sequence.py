@@ -94,16 +94,22 @@ def main():
     ap.add_argument("--device", default=None)
     ap.add_argument("--no-vote", action="store_true")
     ap.add_argument("--seg", action="store_true", help="stage-2 model StreamMOS_seg (488-tensor checkpoint)")
+    ap.add_argument("--instance-vote", action="store_true",
+                    help="voxel_instance_voting.py instead of voxel_voting.py for the refined labels (needs --seg: the "
+                         "clusters come from the `_bf` prediction)")
     ap.add_argument("--limit", type=int, default=None)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = args.device or "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     lengths = {d: len(os.listdir(os.path.join(d, "velodyne"))) for d in args.seq_dir}
     mine = streaming.shard_sequences(lengths, world)[rank]
+    if args.instance_vote and not args.seg:
+        ap.error("--instance-vote needs --seg")
     model = load_model(args.checkpoint, device, seg=args.seg)
+    vote = False if args.no_vote else ("instance" if args.instance_vote else True)
     for d in mine:
         out = os.path.join(args.out_dir, os.path.basename(os.path.normpath(d))) if len(args.seq_dir) > 1 else args.out_dir
-        print(json.dumps(run_sequence(model, d, out, device, vote=not args.no_vote, limit=args.limit)), flush=True)
+        print(json.dumps(run_sequence(model, d, out, device, vote=vote, limit=args.limit)), flush=True)
 
 
 if __name__ == "__main__":

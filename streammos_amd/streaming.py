@@ -94,6 +94,87 @@ class VoxelVoter:
         return []
 
 
+class InstanceVoter(VoxelVoter):
+    """Voxel voting followed by the instance-level vote of voxel_instance_voting.py:195-272.
+
+    ``push`` additionally takes the frame's movable-object prediction (the `_bf` labels of StreamMOS_seg, 2 =
+    foreground).  Per voted frame: the foreground points are clustered with DBSCAN(0.3, 5) on the device
+    (ops.dbscan), clusters of more than 30 points get an axis-aligned box whose floor is lifted by 0.2 m, the class-1 /
+    class-2 points of the local map inside each box are counted on the device (ops.box_vote; the local map is the
+    pose-aligned, cropped window with its PRE-vote predictions) and every point of the cluster takes class 2 if
+    2 * n2 > n1 (the reference sums label VALUES, :178-179) else class 1.  torch is used for the small bookkeeping in
+    between (compaction, per-cluster min / max); the DBSCAN call synchronises the stream."""
+
+    EPS, MIN_SAMPLES, MIN_POINTS, FLOOR_LIFT = 0.3, 5, 30, 0.2
+
+    def __init__(self, device, window=VOTE_WINDOW, lut=LEARNING_MAP_INV, recip_quantize=False):
+        super().__init__(device, window=window, lut=lut, recip_quantize=recip_quantize)
+        self.bf = {}
+
+    def reset(self):
+        super().reset()
+        self.bf.clear()
+
+    def push(self, points, preds, pose, bf=None):
+        if bf is None:
+            raise RuntimeError("InstanceVoter.push needs the movable-object (`_bf`) labels of the frame")
+        self.bf[self.next_id] = bf
+        ready = super().push(points, preds, pose)
+        for k in [k for k in self.bf if k not in self.frames]:
+            del self.bf[k]
+        return ready
+
+    def cluster_boxes(self, fpts):
+        """fpts [m,3] float32 foreground points -> (member [m] bool, slot [m] long into the kept clusters, boxes [K,6])."""
+        names = ops.dbscan(fpts, self.EPS, self.MIN_SAMPLES)
+        valid = names >= 0
+        empty = (valid & False, torch.zeros_like(names, dtype=torch.long), fpts.new_zeros((0, 6)))
+        if not bool(valid.any()):
+            return empty
+        uniq, inv, counts = torch.unique(names[valid], return_inverse=True, return_counts=True)
+        keep = counts > self.MIN_POINTS                                   # :165
+        if not bool(keep.any()):
+            return empty
+        k = uniq.numel()
+        idx = inv[:, None].expand(-1, 3)
+        lo = fpts.new_full((k, 3), float("inf")).scatter_reduce_(0, idx, fpts[valid], "amin")
+        hi = fpts.new_full((k, 3), float("-inf")).scatter_reduce_(0, idx, fpts[valid], "amax")
+        lo, hi = lo[keep], hi[keep]
+        lifted = lo[:, 2] + self.FLOOR_LIFT                               # :171-173: corners at z_min move up, in float32
+        flat = hi[:, 2] == lo[:, 2]                                       # every corner is at z_min: the whole box moves
+        z0, z1 = torch.minimum(lifted, hi[:, 2]), torch.maximum(lifted, hi[:, 2])
+        boxes = torch.stack((lo[:, 0], lo[:, 1], z0, hi[:, 0], hi[:, 1], z1), dim=1)
+        # a box without volume is "not a hull" for the reference's Delaunay test (:72-74): it contains nothing
+        degenerate = flat | (boxes[:, 3:] == boxes[:, :3]).any(dim=1)
+        boxes[degenerate, :3] = float("inf")
+        slot_of = torch.full((k,), -1, dtype=torch.long, device=fpts.device)
+        slot_of[keep] = torch.arange(int(keep.sum()), device=fpts.device)
+        slot = torch.full_like(names, -1, dtype=torch.long)
+        slot[valid] = slot_of[inv]
+        return slot >= 0, slot, boxes.contiguous()
+
+    def _vote(self, fid):
+        pts, pred, pose = self.frames[fid]
+        inv_cur = np.linalg.inv(pose)
+        history = [(h, inv_cur.dot(self.frames[h][2])) for h in vote_history_ids(fid, self.window) if h in self.frames]
+        ops.vote_clear(self.table)
+        for h, diff in history:
+            ops.vote_accumulate(self.frames[h][0], self.frames[h][1], self.table, pose_diff=diff, recip_quantize=self.recip)
+        ops.vote_accumulate(pts, pred, self.table, recip_quantize=self.recip)
+        labels = ops.vote_resolve(pts, pred, self.table, lut=None, recip_quantize=self.recip)
+        fg = torch.nonzero(self.bf[fid] == 2).flatten()                   # :145
+        if fg.numel() > 0:
+            member, slot, boxes = self.cluster_boxes(pts[fg][:, :3].contiguous())
+            if boxes.shape[0] > 0:
+                counts = torch.zeros((boxes.shape[0], 3), dtype=torch.int32, device=self.device)
+                for h, diff in history:
+                    ops.box_vote(self.frames[h][0], self.frames[h][1], boxes, counts, pose_diff=diff)
+                ops.box_vote(pts, pred, boxes, counts)
+                verdict = torch.where(2 * counts[:, 2] > counts[:, 1], 2, 1).to(torch.int32)   # :178-183
+                labels[fg[member]] = verdict[slot[member]]
+        return self.lut[labels.long()] if self.lut is not None else labels
+
+
 class StreamRunner:
     """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
 
@@ -105,7 +186,11 @@ class StreamRunner:
         the CUs the other group leaves idle.  Voting stays outside the graphs (pose matrices are launch arguments)."""
         self.device = torch.device(device)
         self.model = model.to(self.device).eval()
-        self.voter = VoxelVoter(self.device, recip_quantize=recip_quantize) if vote else None
+        # vote: False / True (voxel voting) / "instance" (voxel + instance voting; needs the StreamMOS_seg model)
+        if vote == "instance":
+            self.voter = InstanceVoter(self.device, recip_quantize=recip_quantize)
+        else:
+            self.voter = VoxelVoter(self.device, recip_quantize=recip_quantize) if vote else None
         self.use_graph = graph
         self.split = max(1, int(split))
         self._graphs = None
@@ -267,14 +352,22 @@ class StreamRunner:
         elif "valid_index" in dev:
             raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
             raw.index_copy_(0, dev["valid_index"], labels[:dev["n_valid"]])      # val_StreamMOS.py:112-118
-        if bf_labels is not None and "valid_index" in dev:       # the `_bf` prediction file of val_StreamMOS_seg.py:128-131,141
+        if bf_labels is not None and "prefix" in dev:
+            out["bf_raw_labels"] = self._pre.unpad_labels(bf_labels, dev)
+        elif bf_labels is not None and "valid_index" in dev:     # the `_bf` prediction file of val_StreamMOS_seg.py:128-131,141
             bf_raw = torch.zeros(dev["n_raw"], dtype=torch.uint8, device=self.device)
             bf_raw.index_copy_(0, dev["valid_index"], bf_labels[:dev["n_valid"]])
             out["bf_raw_labels"] = bf_raw
         if raw is not None:
             out["raw_labels"] = raw
             if self.voter is not None and "raw_scan" in dev:
-                out["voted"] = self.voter.push(dev["raw_scan"], raw, pose if pose is not None else np.eye(4))
+                pose = pose if pose is not None else np.eye(4)
+                if isinstance(self.voter, InstanceVoter):
+                    if "bf_raw_labels" not in out:
+                        raise RuntimeError("instance voting needs the `_bf` prediction of the StreamMOS_seg model")
+                    out["voted"] = self.voter.push(dev["raw_scan"], raw, pose, out["bf_raw_labels"])
+                else:
+                    out["voted"] = self.voter.push(dev["raw_scan"], raw, pose)
         self.frame += 1
         return out
 
