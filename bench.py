@@ -205,6 +205,7 @@ def main():
     with profiling.kernel_timer(only=dominant) as kt:
         for i in range(args.steps):
             one_step(args.warmup + i)
+        enqueue = time.perf_counter() - t0     # host time to issue all steps (the GPU may still be running)
         sync()
         elapsed = time.perf_counter() - t0
     timed = kt.summary()
@@ -258,6 +259,7 @@ def main():
                                       "frac": round(value / world * ALG_TFLOP_PER_SCAN / FP32_PEAK_TFLOPS, 4),
                                       "note": "the path computes in fp32 like the reference: 0.53 TFLOP/scan against the fp32 "
                                               "MFMA/vector peak is the ceiling that binds first (296 scans/s), not HBM"},
+            "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if world == 1:

@@ -141,15 +141,17 @@ int smos_vote_resolve(const float* pts, int64_t n, int64_t pt_stride, const uint
  *   noise.  scikit-learn numbers clusters 0,1,2.. in the order of exactly that index, so ranking the distinct names
  *   gives its labels; a border point gets the smallest name among the clusters it touches (the one scikit-learn expands
  *   first).  Distances: float32 coordinates widened to float64, d2 = dx*dx + dy*dy + dz*dz, d2 <= eps*eps.
- *   work: device scratch of n + 1 int32.  The call synchronises `stream` once per propagation sweep (it reads back a
- *   "changed" flag); max_sweeps bounds the loop (a chain of n core points needs O(log n) .. O(n) sweeps).
+ *   work: device scratch of smos_dbscan_work_bytes(n) bytes, 256-byte aligned (x-sorted copy of the points, the
+ *   permutation, labels, hipCUB sort space).  The call synchronises `stream` once per 4 propagation sweeps (it reads
+ *   back a "changed" flag); max_sweeps bounds the loop.
  * smos_box_vote: counts[k*3 + c] (device, uint32, caller zero-fills) += number of points of class c in {1,2} of one
  *   frame that survive the voting crop (utils/transforms.py:151-161) and lie inside the closed axis-aligned box
  *   boxes[k] = (lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) float32 -- in_hull() of :62-76 for a box.  pose_diff as in
  *   smos_vote_accumulate (NULL for the current frame).  At most 2048 boxes per call.
  */
+int64_t smos_dbscan_work_bytes(int64_t n);   /* 0 for n == 0, -1 on failure */
 int smos_dbscan(const float* pts, int64_t n, int64_t pt_stride, double eps, int32_t min_samples, int32_t* labels,
-                int32_t* work, int32_t max_sweeps, smos_stream_t stream);
+                void* work, int64_t work_bytes, int32_t max_sweeps, smos_stream_t stream);
 int smos_box_vote(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels, const double* pose_diff,
                   const float* boxes, int32_t K, uint32_t* counts, smos_stream_t stream);
 

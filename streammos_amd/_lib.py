@@ -28,7 +28,8 @@ SIGNATURES = {
     "smos_vote_clear": [vp, vp],
     "smos_vote_accumulate": [vp, i64, i64, vp, c_f64p, i32, vp, vp],
     "smos_vote_resolve": [vp, i64, i64, vp, i32, vp, vp, vp, vp],
-    "smos_dbscan": [vp, i64, i64, ctypes.c_double, i32, vp, vp, i32, vp],
+    "smos_dbscan_work_bytes": [i64],
+    "smos_dbscan": [vp, i64, i64, ctypes.c_double, i32, vp, vp, i64, i32, vp],
     "smos_box_vote": [vp, i64, i64, vp, c_f64p, vp, i32, vp, vp],
     "smos_bias_act": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_downsample_epilogue": [vp, c_i64p, vp, c_i64p, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
@@ -71,6 +72,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p
     _lib = lib

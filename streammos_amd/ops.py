@@ -219,11 +219,15 @@ def dbscan(points, eps, min_samples, max_sweeps=4096):
     labels = torch.empty(n, dtype=torch.int32, device=points.device)
     if n == 0:
         return labels
-    work = torch.empty(n + 1, dtype=torch.int32, device=points.device)
     lib = _lib.load()
+    need = int(lib.smos_dbscan_work_bytes(n))
+    if need <= 0:
+        raise RuntimeError("dbscan: workspace query failed for n=%d" % n)
+    work = torch.empty(need + 256, dtype=torch.uint8, device=points.device)
+    base = (work.data_ptr() + 255) // 256 * 256
     with torch.cuda.device(points.device):
         rc = lib.smos_dbscan(points.data_ptr(), n, points.stride(0), float(eps), int(min_samples), labels.data_ptr(),
-                             work.data_ptr(), int(max_sweeps), _stream(points))
+                             base, need, int(max_sweeps), _stream(points))
     _lib.check(rc, "smos_dbscan")
     return labels
 
