@@ -61,6 +61,15 @@ def algorithmic_bytes(label):
     if name == "msda_fwd":
         n, lq, m, d = (int(v) for v in dims.split("x"))
         return 4 * (n * lq * m * d * 2 + n * lq * m * 4 * 3)
+    if name in ("stem_gemm", "stem_epilogue", "stem_mark+compact"):
+        # sparse DownSample2D 192 -> 32, stride 2: the dense op it replaces reads the grid once and writes the half-
+        # resolution map; the three spans of the sparse form share that figure (gemm: grid in; epilogue: map out)
+        b, h, w, cin = (int(v) for v in dims.split("x"))
+        if name == "stem_gemm":
+            return 4 * b * h * w * cin
+        if name == "stem_epilogue":
+            return 4 * b * (h // 2) * (w // 2) * 32
+        return 4 * b * h * w
     return 0
 
 

@@ -199,6 +199,31 @@ int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, cons
                           const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b, int64_t po_n,
                           int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin, int32_t cmid,
                           int32_t cout, smos_stream_t stream);
+/* Sparse DownSample2D on the input grid (networks/backbone.py:136-159 as used by header_bev[0],
+ * multi_view_encoder.py:340-347): see csrc/stem.hip.  All buffers are device memory owned by the caller; no call reads
+ * anything back to the host (row counts stay in `meta`), so the sequence is graph-capturable.
+ *   smos_stem_mark    flags (int32 [4, B, H/2, W/2], caller zero-fills; index = parity class (y&1)*2+(x&1), sample,
+ *                     y>>1, x>>1) <- 1 for every cell a point of coord [B, T, N, K] falls into.
+ *   smos_stem_compact scan <- exclusive prefix sum of flags (scan_ws: smos_stem_scan_bytes(B*H*W) bytes of scratch);
+ *                     row_cell[row] <- natural cell id (b*H + y)*W + x; row_of [B,H,W] <- row id or -1;
+ *                     meta (12 x int32): [0..3] rows per class, [4..7] first row of each class.
+ *   smos_stem_gemm    y4[cls] (device, capacity B*(H/2)*(W/2) rows of (taps+1)*Cout floats; taps = 1,2,2,4) <-
+ *                     occupied rows of bev [B*H*W, Cin] times the class weights.  wprep4[cls]: weights of the class in
+ *                     MFMA operand order [(taps+1)][Cin/2][64]: entry (mt, s, lane) = W[mt*32 + (lane & 31)][(lane >> 5) *
+ *                     (Cin/2) + s], where W stacks the class's 3x3 taps (ky-major over the kernel rows / columns that
+ *                     reach an output pixel) and the 1x1 pool-branch weights last.  Built for Cin = 192, Cout = 32.
+ *   smos_stem_epilogue out[b,ho,wo,c] <- relu(sum_taps Y[cell][slot][c] + max_window(occupied ? Y[cell][q][c] : 0) +
+ *                     bias[c]); out is channels-last [B, H/2, W/2, *] with row pitch out_pitch; C must be 32.
+ * y4 / wprep4 are HOST arrays of 4 device pointers. */
+int smos_stem_mark(const float* coord, int32_t K, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t* flags,
+                   smos_stream_t stream);
+int64_t smos_stem_scan_bytes(int64_t cells);
+int smos_stem_compact(const int32_t* flags, int64_t B, int64_t H, int64_t W, int32_t* scan, void* scan_ws, int64_t scan_ws_bytes,
+                      int32_t* row_cell, int32_t* row_of, int32_t* meta, smos_stream_t stream);
+int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4, float* const* y4,
+                   int64_t Cin, int64_t Cout, smos_stream_t stream);
+int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
+                       int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream);
 /* BilinearSample (networks/backbone.py:453-475) of grid [B,C,Hg,Wg] (element strides grid_stride[4]) at
  * gcoord*gscale, fused with VoxelMaxPool of the result into out [B,Ho,Wo,C] (channels-last) at
  * int(scoord*sscale) (networks/multi_view_encoder.py:395-404,410-419).  out may be NULL (gather only);

@@ -35,6 +35,11 @@ SIGNATURES = {
     "smos_downsample_epilogue": [vp, c_i64p, vp, c_i64p, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
     "smos_channel_gate_residual": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, vp],
     "smos_pointnet_scatter": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
+    "smos_stem_mark": [vp, i32, i64, i64, i64, i64, i64, vp, vp],
+    "smos_stem_scan_bytes": [i64],
+    "smos_stem_compact": [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp],
+    "smos_stem_gemm": [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), i64, i64, vp],
+    "smos_stem_epilogue": [ctypes.POINTER(vp), vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],
@@ -73,6 +78,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
+    lib.smos_stem_scan_bytes.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p
     _lib = lib

@@ -14,6 +14,8 @@ tensors; on a GPU in eval mode they hand over to this engine, which computes the
 The engine holds *copies* of the folded weights: it is rebuilt whenever the module's parameters may have
 changed (``load_state_dict``, ``.to()``, ``.train()``), see ``AttNet._engine_for``.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -64,6 +66,14 @@ class InferenceEngine:
         self.pp2 = _fold(l1[0].weight, None, l1[1])
 
         self.header_bev = [self._block(m) for m in enc.header_bev]
+        # sparse first stage (csrc/stem.hip): per parity class of the input cell, the kernel taps that can reach an
+        # output pixel under stride 2, stacked with the 1x1 pool-branch weights, in MFMA operand order
+        self.sparse_stem = os.environ.get("SMOS_SPARSE_STEM", "1") != "0"     # A/B switch (AttNet.engine_sparse_stem overrides)
+        self.stem_w = None
+        p0 = self.header_bev[0]
+        if (p0.kind == "down" and p0.stride == 2 and p0.wa.shape[0] == 32 and p0.wa.shape[1] == 192 and
+                tuple(p0.wa.shape[2:]) == (3, 3)):
+            self.stem_w = ops.stem_prepare_weights(p0.wa, p0.wp)
         self.header_rv = [self._block(m) for m in enc.header_rv]
         self.res1_bev = [self._block(m) for m in enc.res1_bev]
         self.res1_rv = [self._block(m) for m in enc.res1_rv]
@@ -341,6 +351,11 @@ class InferenceEngine:
         back.zero_()
         ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows)
 
+    def _stem_sparse_cl(self, bev_cl, pcds_coord):
+        """header_bev[0] on the occupied cells only (csrc/stem.hip).  bev_cl [B,H,W,Cin] channels-last scatter target,
+        pcds_coord [B,T,N,3,1]."""
+        return ops.sparse_downsample(bev_cl, pcds_coord, self.stem_w, self.header_bev[0].bias)
+
     def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord):
         bs, t, cin, n, _ = point_feat.shape
         dev = point_feat.device
@@ -356,7 +371,11 @@ class InferenceEngine:
                              pts_out=fuse[:, :, :o1], zero_fill=True)
         c0 = self.header_bev[-1].w2.shape[0]
         x0cat = ops.empty_cl(bs, 2 * c0, hb // 2, wb // 2, dev)
-        self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
+        if self.sparse_stem and self.stem_w is not None:
+            x = self._stem_sparse_cl(bev_cl, pcds_coord)
+            self._stage_cl(x, self.header_bev[1:], out=x0cat[:, :c0])
+        else:
+            self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
         self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
         x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
         self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])

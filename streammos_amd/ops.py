@@ -3,6 +3,8 @@
 torch is used for device memory and streams only: every function launches on
 ``torch.cuda.current_stream`` of the tensors' device and returns without synchronising.
 """
+import ctypes
+
 import torch
 
 from . import _lib, profiling
@@ -372,6 +374,66 @@ def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None, zero_fill=F
                                        po_b, po_n, b, t, n, h, w, cin, w1.shape[0], cout, _stream(xyzi))
     _lib.check(rc, "smos_pointnet_scatter")
     return bev
+
+
+STEM_TAPS = (1, 2, 2, 4)      # 3x3 taps that reach an output pixel under stride 2, per parity class (y&1)*2 + (x&1)
+
+
+def stem_prepare_weights(wa, wp):
+    """wa [Cout,Cin,3,3], wp [Cout,Cin,1,1] (BatchNorm folded) -> 4 tensors in the MFMA operand order smos_stem_gemm
+    expects: [(taps+1), Cin/2, 64], entry (mt, s, lane) = W[mt*32 + (lane & 31)][(lane >> 5) * (Cin/2) + s]."""
+    cout, cin = wa.shape[0], wa.shape[1]
+    out = []
+    for cls in range(4):
+        ey, ex = cls >> 1, cls & 1
+        kys, kxs = ((0, 2) if ey else (1,)), ((0, 2) if ex else (1,))
+        w = torch.cat([wa[:, :, ky, kx] for ky in kys for kx in kxs] + [wp[:, :, 0, 0]], 0).float()      # [(taps+1)*Cout, Cin]
+        km = w.shape[0] // 32
+        out.append(w.view(km, 32, 2, cin // 2).permute(0, 3, 2, 1).reshape(km, cin // 2, 64).contiguous())
+    return out
+
+
+def sparse_downsample(bev_cl, coord, wprep, bias, out=None):
+    """DownSample2D(stride 2) of the channels-last scatter target bev_cl [B,H,W,Cin] on its occupied cells only
+    (csrc/stem.hip): mark -> compact -> per-class MFMA GEMM -> per-pixel assembly.  coord [B,T,N,K(,1)] are the point
+    coordinates the grid was scattered with.  Returns the channels-last [B,Cout,H/2,W/2] view.  No host synchronisation."""
+    _require_cuda("sparse_downsample", bev_cl, coord, bias, out, *wprep)
+    b, h, w, cin = bev_cl.shape
+    dev = bev_cl.device
+    if bev_cl.dtype != torch.float32 or not bev_cl.is_contiguous() or coord.dtype != torch.float32 or not coord.is_contiguous():
+        raise RuntimeError("sparse_downsample: bev_cl and coord must be contiguous float32")
+    t, n, k = coord.shape[1], coord.shape[2], coord.shape[3]
+    cout = bias.shape[0]
+    cells, per = b * h * w, b * (h // 2) * (w // 2)
+    lib = _lib.load()
+    scan_bytes = int(lib.smos_stem_scan_bytes(cells))
+    if scan_bytes < 0:
+        raise RuntimeError("sparse_downsample: scan workspace query failed")
+    flags = torch.zeros(cells, dtype=torch.int32, device=dev)
+    scan = torch.empty(cells, dtype=torch.int32, device=dev)
+    scan_ws = torch.empty(max(scan_bytes, 1), dtype=torch.uint8, device=dev)
+    row_cell = torch.empty(cells, dtype=torch.int32, device=dev)
+    row_of = torch.empty(cells, dtype=torch.int32, device=dev)
+    meta = torch.zeros(12, dtype=torch.int32, device=dev)
+    ys = [torch.empty((per, (taps + 1) * cout), dtype=torch.float32, device=dev) for taps in STEM_TAPS]   # worst-case capacity
+    if out is None:
+        out = empty_cl(b, cout, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, dev)
+    y_ptrs = (ctypes.c_void_p * 4)(*[y.data_ptr() for y in ys])
+    w_ptrs = (ctypes.c_void_p * 4)(*[wt.data_ptr() for wt in wprep])
+    st = _stream(bev_cl)
+    tag = "[%dx%dx%dx%d]" % (b, h, w, cin)
+    with torch.cuda.device(dev):
+        with profiling.span("stem_mark+compact" + tag):
+            _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), st), "smos_stem_mark")
+            _lib.check(lib.smos_stem_compact(flags.data_ptr(), b, h, w, scan.data_ptr(), scan_ws.data_ptr(), scan_ws.numel(),
+                                             row_cell.data_ptr(), row_of.data_ptr(), meta.data_ptr(), st), "smos_stem_compact")
+        with profiling.span("stem_gemm" + tag):
+            _lib.check(lib.smos_stem_gemm(bev_cl.data_ptr(), row_cell.data_ptr(), meta.data_ptr(), w_ptrs, y_ptrs, cin, cout, st),
+                       "smos_stem_gemm")
+        with profiling.span("stem_epilogue" + tag):
+            _lib.check(lib.smos_stem_epilogue(y_ptrs, meta.data_ptr(), row_of.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                              _cl("sparse_downsample", out), b, h, w, cout, st), "smos_stem_epilogue")
+    return out
 
 
 def gather_scatter(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None):

@@ -84,6 +84,8 @@ class AttNet(nn.Module):
             from ... import engine
             self._engine = engine.InferenceEngine(self, layout=self.engine_layout)
         self._engine.miopen_search = self.engine_miopen_search
+        if getattr(self, "engine_sparse_stem", None) is not None:
+            self._engine.sparse_stem = bool(self.engine_sparse_stem)
         return self._engine
 
     # ------------------------------------------------------------------------------------

@@ -120,6 +120,42 @@ def test_fused_engine_equals_module_graph(model):
                 assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
 
 
+@pytest.mark.parametrize("fill", ["lidar", "empty_sample", "dense_corner"])
+def test_sparse_stem_equals_dense_downsample(model, fill):
+    """header_bev[0] computed on the occupied cells only (stem_mark + per-parity-class GEMMs + stem_epilogue) against
+    the dense conv3x3 s2 / conv1x1 + maxpool formulation on the same grid.  fp32 both ways, different summation order:
+    1e-5 of the output range.  Covers image borders, all four parity classes, a sample without points and a fully
+    occupied region."""
+    from streammos_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    b, t, n, h, w = 2, 3, 6000, 512, 512
+    eng = model._engine_for(torch.zeros(1, device=DEV)) if False else None
+    with torch.no_grad():
+        eng = model._engine_for(torch.zeros(1, device=DEV))
+    assert eng is not None and eng.stem_w is not None
+    coord = torch.rand((b, t, n, 3, 1), generator=gen) * 540.0 - 14.0          # some points outside the grid
+    coord[0, :, :200, 0] = torch.rand((t, 200, 1), generator=gen) * 1.9 - 0.95   # rows -1 < y < 1 (top border, cell 0)
+    coord[0, :, 200:400, 1] = 511.0 + torch.rand((t, 200, 1), generator=gen) * 0.99
+    if fill == "empty_sample":
+        coord[1] = -100.0
+    if fill == "dense_corner":
+        yy, xx = torch.meshgrid(torch.arange(40.0), torch.arange(50.0), indexing="ij")
+        blockc = torch.stack((yy.reshape(-1) + 0.5, xx.reshape(-1) + 0.5, torch.zeros(2000)), 1)
+        coord[1, 0, :2000, :, 0] = blockc
+    coord = coord.to(DEV)
+    xyzi = torch.randn((b, t, 7, n, 1), generator=gen).to(DEV)
+    bev_cl = torch.zeros((b, h, w, t * 64), device=DEV)
+    ops.pointnet_scatter(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], bev_cl)
+    with torch.no_grad(), eng._conv_flags():
+        want = eng._block_cl(bev_cl.permute(0, 3, 1, 2), eng.header_bev[0])
+        got = eng._stem_sparse_cl(bev_cl, coord)
+    assert got.shape == want.shape
+    scale = want.abs().max().item()
+    assert scale > 0
+    assert (got - want).abs().max().item() <= 1e-5 * scale
+    assert ((got > 0) == (want > 0)).float().mean().item() > 0.9999
+
+
 def test_engine_is_dropped_when_weights_change(model):
     import copy
     m = copy.deepcopy(model)
