@@ -208,7 +208,8 @@ int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, cons
  *                     row_cell[row] <- natural cell id (b*H + y)*W + x; row_of [B,H,W] <- row id or -1;
  *                     meta (12 x int32): [0..3] rows per class, [4..7] first row of each class.
  *   smos_stem_gemm    y4[cls] (device, capacity B*(H/2)*(W/2) rows of (taps+1)*Cout floats; taps = 1,2,2,4) <-
- *                     occupied rows of bev [B*H*W, Cin] times the class weights.  wprep4[cls]: weights of the class in
+ *                     occupied rows of bev [B*H*W, Cin] times the class weights; with row_cell == NULL, bev is the
+ *                     compact row table itself (row r of the table = global row r).  wprep4[cls]: weights of the class in
  *                     MFMA operand order [(taps+1)][Cin/2][64]: entry (mt, s, lane) = W[mt*32 + (lane & 31)][(lane >> 5) *
  *                     (Cin/2) + s], where W stacks the class's 3x3 taps (ky-major over the kernel rows / columns that
  *                     reach an output pixel) and the 1x1 pool-branch weights last.  Built for Cin = 192, Cout = 32.
@@ -220,10 +221,19 @@ int smos_stem_mark(const float* coord, int32_t K, int64_t B, int64_t T, int64_t 
 int64_t smos_stem_scan_bytes(int64_t cells);
 int smos_stem_compact(const int32_t* flags, int64_t B, int64_t H, int64_t W, int32_t* scan, void* scan_ws, int64_t scan_ws_bytes,
                       int32_t* row_cell, int32_t* row_of, int32_t* meta, smos_stream_t stream);
+/* rows[0 .. meta[11]) <- 0 (row_floats floats per row): the zero fill of the compact row table of
+ * smos_pointnet_scatter_rows, sized on the device. */
+int smos_stem_zero_rows(float* rows, const int32_t* meta, int64_t row_floats, smos_stream_t stream);
 int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4, float* const* y4,
                    int64_t Cin, int64_t Cout, smos_stream_t stream);
 int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
                        int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream);
+/* smos_pointnet_scatter with a COMPACT target: rows [n_rows, T*cout] (zero-filled by smos_stem_zero_rows) instead of
+ * the dense [B,H,W,T*cout] grid; the features of cell (b, y, x) go to row row_of[b][y][x] (smos_stem_compact). */
+int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
+                               int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                               int32_t cmid, int32_t cout, smos_stream_t stream);
 /* BilinearSample (networks/backbone.py:453-475) of grid [B,C,Hg,Wg] (element strides grid_stride[4]) at
  * gcoord*gscale, fused with VoxelMaxPool of the result into out [B,Ho,Wo,C] (channels-last) at
  * int(scoord*sscale) (networks/multi_view_encoder.py:395-404,410-419).  out may be NULL (gather only);

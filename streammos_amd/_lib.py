@@ -40,6 +40,8 @@ SIGNATURES = {
     "smos_stem_compact": [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp],
     "smos_stem_gemm": [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), i64, i64, vp],
     "smos_stem_epilogue": [ctypes.POINTER(vp), vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
+    "smos_pointnet_scatter_rows": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
+    "smos_stem_zero_rows": [vp, vp, i64, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],

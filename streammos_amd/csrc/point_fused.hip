@@ -71,7 +71,8 @@ struct PnsArgs {
   const float* b1;     // [64]
   const float* w2;     // [64, 64]
   const float* b2;     // [64]
-  float* bev;          // [B, H, W, T*64] zero-filled
+  float* bev;          // [B, H, W, T*64] zero-filled; or, with row_of, compact rows [n_rows, T*64]
+  const int32_t* row_of;  // null, or [B, H, W] row of every occupied cell (csrc/stem.hip): scatter into compact rows
   float* pts_out;      // [B, N, *] rows of the t == 0 sample (row pitch po_n), or null
   int64_t bev_sb, po_b, po_n;
   int S, T, N, K, H, W, tiles_per_sample;
@@ -152,14 +153,19 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     in.cx = has ? cr[col * a.K + 1] : -1.0f;
   };
 
-  auto cell_of = [&](const TileIn& in) {
+  // target slot of the lane's point: its cell of the dense grid, or (compact target) the row of that cell -- looked up
+  // here, per lane and inside the prefetch shadow, not in the serial flush loop.  Equal cells <=> equal rows, so the
+  // run detection works on either.
+  auto cell_of = [&](const TileIn& in, int tile) {
     const float yx[2] = {in.cy, in.cx};
-    return cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
+    int c = cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
+    if (a.row_of && c >= 0) c = a.row_of[(int64_t)((tile / nt_per_sample) / a.T) * a.H * a.W + c];
+    return c;
   };
   int nt = (int)blockIdx.x * (kBlock / kWave) + wave_u;
   TileIn cur;
   fetch(nt, cur);
-  int cell = cell_of(cur);
+  int cell = cell_of(cur, nt);
   for (; nt < n_nt; nt += nt_step) {
     // Software pipeline: the next tile's loads are issued here and waited for after this tile's matrix phase, BEFORE
     // this tile's stores and atomics are issued.  The vector-memory counter of gfx9 retires in order and the number of
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     for (int i = 0; i < kNt; ++i) v[i] = tile[i * kPitchM + lane];
     // the prefetch is waited for here (tied to the last LDS read so that the scheduler cannot hoist the wait)
     asm volatile("" : "+v"(nxt.x[0]), "+v"(nxt.x[1]), "+v"(nxt.x[2]), "+v"(nxt.x[3]), "+v"(nxt.cy), "+v"(nxt.cx), "+v"(v[kNt - 1]));
-    const int cell_next = cell_of(nxt);
+    const int cell_next = cell_of(nxt, nt + nt_step);
     if (a.pts_out && t == 0) {
       float* prow = a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n;   // wave-uniform
       if (n_valid == kNt) {
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
           if (i < n_valid) (prow + (int64_t)i * a.po_n)[ulane] = v[i];
       }
     }
-    float* gsample = a.bev + (int64_t)b * a.bev_sb + t * 64;   // wave-uniform
+    // wave-uniform target of this (sample, scan): the sample's slab of the dense grid, or the compact row table
+    float* gsample = a.bev + (a.row_of ? (int64_t)0 : (int64_t)b * a.bev_sb) + t * 64;
     const int64_t cell_pitch = (int64_t)a.T * 64;
     float best = 0.0f;
 #pragma unroll
@@ -365,10 +372,10 @@ __global__ __launch_bounds__(kBlock) void nhwc_to_nchw(const float* __restrict__
 
 using namespace smos;
 
-extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
-                                     const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b,
-                                     int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
-                                     int32_t cmid, int32_t cout, smos_stream_t stream) {
+static int pointnet_scatter_launch(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                   const float* w2, const float* b2, float* bev, const int32_t* row_of, float* pts_out,
+                                   int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                                   int32_t cmid, int32_t cout, smos_stream_t stream) {
   if (cin != 7 || cmid != 64 || cout != 64) {
     set_error("pointnet_scatter: built for the 7 -> 64 -> 64 point MLP (got %d -> %d -> %d)", (int)cin, (int)cmid, (int)cout);
     return SMOS_ERR_UNSUPPORTED;
@@ -377,7 +384,7 @@ extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int3
   SMOS_REQUIRE(xyzi && coord && w1 && b1 && w2 && b2 && bev, "pointnet_scatter: null pointer");
   SMOS_REQUIRE(H * W < (1LL << 31) && (!pts_out || po_n >= 64), "pointnet_scatter: bad geometry");
   PnsArgs a;
-  a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.pts_out = pts_out;
+  a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.row_of = row_of; a.pts_out = pts_out;
   a.bev_sb = H * W * T * 64; a.po_b = po_b; a.po_n = po_n;
   a.S = (int)(B * T); a.T = (int)T; a.N = (int)N; a.K = K; a.H = (int)H; a.W = (int)W;
   a.tiles_per_sample = (int)((N + kNt - 1) / kNt);
@@ -399,6 +406,23 @@ extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int3
   hipLaunchKernelGGL(pointnet_scatter, dim3((unsigned)(want < resident ? want : resident)), dim3(kBlock), 0,
                      (hipStream_t)stream, a);
   return check_launch("pointnet_scatter");
+}
+
+extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                     const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b,
+                                     int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                                     int32_t cmid, int32_t cout, smos_stream_t stream) {
+  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, bev, nullptr, pts_out, po_b, po_n, B, T, N, H, W, cin, cmid, cout,
+                                 stream);
+}
+
+extern "C" int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                          const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
+                                          int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W,
+                                          int32_t cin, int32_t cmid, int32_t cout, smos_stream_t stream) {
+  SMOS_REQUIRE(row_of, "pointnet_scatter_rows: null row table");
+  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, rows, row_of, pts_out, po_b, po_n, B, T, N, H, W, cin, cmid, cout,
+                                 stream);
 }
 
 extern "C" int smos_gather_scatter(const float* grid, const int64_t* grid_stride, const float* gcoord, int32_t Kg,

@@ -66,6 +66,13 @@ __global__ void stem_meta(int32_t* meta) {
   if (threadIdx.x < 4) meta[threadIdx.x] = meta[8 + threadIdx.x] - meta[4 + threadIdx.x];
 }
 
+// zero-fill of the compact row table: only the rows that exist (their number is on the device)
+__global__ __launch_bounds__(kBlock) void stem_zero_rows(float4* __restrict__ rows, const int32_t* __restrict__ meta, int row_f4) {
+  const int64_t total = (int64_t)meta[11] * row_f4;    // meta[8 + 3] = one past the last row of the last class
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // Y_cls[r][mt*32 + c] = sum_k W_cls[mt*32 + c][k] * X[row_cell[start + r]][k]   (k = 0..191) on the matrix cores, in the
 // transposed form of pointnet_scatter (point_fused.hip): output channel on the MFMA row, cell on the column.
 //   A operand (weights): whole class in LDS as [mt][k-step s][lane], lane (m, h) holding W[mt*32+m][h*96+s];
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(kStemBlock) void stem_gemm(const float* __restrict_
   for (int tile = blockIdx.x * kWaves + wave; tile * 32 < n; tile += gridDim.x * kWaves) {
     const int r = tile * 32 + col;
     const bool valid = r < n;
-    const int32_t cell = valid ? row_cell[start + r] : 0;
+    // row_cell == null: bev already IS the compact row table (smos_pointnet_scatter_rows), row = start + r
+    const int32_t cell = valid ? (row_cell ? row_cell[start + r] : start + r) : 0;
     const float4* src = reinterpret_cast<const float4*>(bev + (int64_t)cell * kStemK + hh * kStemSteps);
     // K in four quarters of 24 steps: the next quarter's 6 float4 of the row are in flight while the current quarter
     // feeds the matrix core (keeping all 96 row values live at once spills under the 256-register budget)
@@ -238,7 +246,7 @@ static void launch_stem_gemm(const float* bev, const int32_t* row_cell, const in
 extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4,
                               float* const* y4, int64_t Cin, int64_t Cout, smos_stream_t stream) {
   SMOS_REQUIRE(Cin == kStemK && Cout == 32, "stem_gemm: built for 192 -> 32 channels");
-  SMOS_REQUIRE(bev && row_cell && meta && wprep4 && y4, "stem_gemm: null pointer");
+  SMOS_REQUIRE(bev && meta && wprep4 && y4, "stem_gemm: null pointer");
   for (int c = 0; c < 4; ++c) SMOS_REQUIRE(wprep4[c] && y4[c], "stem_gemm: null class pointer");
   static int cus = 0;
   if (cus == 0) {
@@ -256,6 +264,14 @@ extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const i
   launch_stem_gemm<3>(bev, row_cell, meta, 2, wprep4[2], y4[2], cus, s);
   launch_stem_gemm<5>(bev, row_cell, meta, 3, wprep4[3], y4[3], cus, s);
   return check_launch("stem_gemm");
+}
+
+extern "C" int smos_stem_zero_rows(float* rows, const int32_t* meta, int64_t row_floats, smos_stream_t stream) {
+  SMOS_REQUIRE(rows && meta && row_floats > 0 && row_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0,
+               "stem_zero_rows: bad arguments");
+  hipLaunchKernelGGL(stem_zero_rows, dim3(256 * 8), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<float4*>(rows), meta,
+                     (int)(row_floats / 4));
+  return check_launch("stem_zero_rows");
 }
 
 extern "C" int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias,

@@ -352,9 +352,10 @@ class InferenceEngine:
         ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows)
 
     def _stem_sparse_cl(self, bev_cl, pcds_coord):
-        """header_bev[0] on the occupied cells only (csrc/stem.hip).  bev_cl [B,H,W,Cin] channels-last scatter target,
-        pcds_coord [B,T,N,3,1]."""
-        return ops.sparse_downsample(bev_cl, pcds_coord, self.stem_w, self.header_bev[0].bias)
+        """header_bev[0] on the occupied cells of a DENSE channels-last grid (csrc/stem.hip); the engine itself scatters
+        into compact rows and never builds the dense grid (_encode_cl), this entry serves tests and A/B runs."""
+        plan = ops.stem_plan(pcds_coord, bev_cl.shape[1], bev_cl.shape[2])
+        return ops.sparse_downsample(bev_cl, plan, self.stem_w, self.header_bev[0].bias, compact=False)
 
     def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord):
         bs, t, cin, n, _ = point_feat.shape
@@ -366,15 +367,20 @@ class InferenceEngine:
         c_dec, c1 = self.conv_2[0].shape[0], self.res1_bev[-1].w2.shape[0]
         o1, o2 = cpt, cpt + c_dec
         fuse = torch.empty((bs, n, cpt + c_dec + c1), dtype=torch.float32, device=dev)
-        bev_cl = torch.empty((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
-        ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
-                             pts_out=fuse[:, :, :o1], zero_fill=True)
         c0 = self.header_bev[-1].w2.shape[0]
         x0cat = ops.empty_cl(bs, 2 * c0, hb // 2, wb // 2, dev)
         if self.sparse_stem and self.stem_w is not None:
-            x = self._stem_sparse_cl(bev_cl, pcds_coord)
+            # sparse first stage: the occupancy of the grid follows from the coordinates alone, so the point MLP scatters
+            # into a compact row table (one row per occupied cell) and the 805 MB dense grid is never built
+            plan = ops.stem_plan(pcds_coord, hb, wb)
+            rows = ops.pointnet_scatter_rows(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1],
+                                             plan, pts_out=fuse[:, :, :o1])
+            x = ops.sparse_downsample(rows, plan, self.stem_w, self.header_bev[0].bias, compact=True)
             self._stage_cl(x, self.header_bev[1:], out=x0cat[:, :c0])
         else:
+            bev_cl = torch.empty((bs, hb, wb, t * cpt), dtype=torch.float32, device=dev)
+            ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
+                                 pts_out=fuse[:, :, :o1], zero_fill=True)
             self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
         self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
         x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)

@@ -393,45 +393,92 @@ def stem_prepare_weights(wa, wp):
     return out
 
 
-def sparse_downsample(bev_cl, coord, wprep, bias, out=None):
-    """DownSample2D(stride 2) of the channels-last scatter target bev_cl [B,H,W,Cin] on its occupied cells only
-    (csrc/stem.hip): mark -> compact -> per-class MFMA GEMM -> per-pixel assembly.  coord [B,T,N,K(,1)] are the point
-    coordinates the grid was scattered with.  Returns the channels-last [B,Cout,H/2,W/2] view.  No host synchronisation."""
-    _require_cuda("sparse_downsample", bev_cl, coord, bias, out, *wprep)
-    b, h, w, cin = bev_cl.shape
-    dev = bev_cl.device
-    if bev_cl.dtype != torch.float32 or not bev_cl.is_contiguous() or coord.dtype != torch.float32 or not coord.is_contiguous():
-        raise RuntimeError("sparse_downsample: bev_cl and coord must be contiguous float32")
-    t, n, k = coord.shape[1], coord.shape[2], coord.shape[3]
-    cout = bias.shape[0]
-    cells, per = b * h * w, b * (h // 2) * (w // 2)
+class StemPlan:
+    """Occupancy of the input grid of one frame (csrc/stem.hip): which cells hold points, in which compact row."""
+
+    def __init__(self, b, h, w, flags, row_cell, row_of, meta):
+        self.b, self.h, self.w = b, h, w
+        self.flags, self.row_cell, self.row_of, self.meta = flags, row_cell, row_of, meta
+
+
+def stem_plan(coord, h, w):
+    """coord [B,T,N,K(,1)] float32 contiguous -> StemPlan: marks the cells the points fall into and compacts them (rows
+    ordered by parity class, sample, position).  Everything stays on the device."""
+    _require_cuda("stem_plan", coord)
+    if coord.dtype != torch.float32 or not coord.is_contiguous():
+        raise RuntimeError("stem_plan: coord must be contiguous float32")
+    b, t, n, k = coord.shape[:4]
+    dev = coord.device
+    cells = b * h * w
     lib = _lib.load()
     scan_bytes = int(lib.smos_stem_scan_bytes(cells))
     if scan_bytes < 0:
-        raise RuntimeError("sparse_downsample: scan workspace query failed")
+        raise RuntimeError("stem_plan: scan workspace query failed")
     flags = torch.zeros(cells, dtype=torch.int32, device=dev)
     scan = torch.empty(cells, dtype=torch.int32, device=dev)
     scan_ws = torch.empty(max(scan_bytes, 1), dtype=torch.uint8, device=dev)
     row_cell = torch.empty(cells, dtype=torch.int32, device=dev)
     row_of = torch.empty(cells, dtype=torch.int32, device=dev)
     meta = torch.zeros(12, dtype=torch.int32, device=dev)
+    st = _stream(coord)
+    with torch.cuda.device(dev), profiling.span("stem_mark+compact[%dx%dx%d]" % (b, h, w)):
+        _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), st), "smos_stem_mark")
+        _lib.check(lib.smos_stem_compact(flags.data_ptr(), b, h, w, scan.data_ptr(), scan_ws.data_ptr(), scan_ws.numel(),
+                                         row_cell.data_ptr(), row_of.data_ptr(), meta.data_ptr(), st), "smos_stem_compact")
+    return StemPlan(b, h, w, flags, row_cell, row_of, meta)
+
+
+def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
+    """pointnet_scatter into the COMPACT row table of `plan`: returns rows [B*H*W (capacity), T*64]; only the first
+    plan.meta[11] rows exist (zero-filled here, on the device-side count) -- the dense grid is never materialised."""
+    _require_cuda("pointnet_scatter_rows", xyzi, coord, w1, b1, w2, b2, pts_out)
+    b, t, cin, n = xyzi.shape[:4]
+    k = coord.shape[3]
+    if not (xyzi.is_contiguous() and coord.is_contiguous()):
+        raise RuntimeError("pointnet_scatter_rows: xyzi and coord must be contiguous")
+    cout = w2.shape[0]
+    rows = torch.empty((plan.b * plan.h * plan.w, t * cout), dtype=torch.float32, device=xyzi.device)
+    po_b = po_n = 0
+    if pts_out is not None:
+        po_b, po_n = _rows("pointnet_scatter_rows", pts_out, cout)
+    lib = _lib.load()
+    st = _stream(xyzi)
+    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
+        _lib.check(lib.smos_stem_zero_rows(rows.data_ptr(), plan.meta.data_ptr(), t * cout, st), "smos_stem_zero_rows")
+        rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                            b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
+                                            pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
+                                            plan.h, plan.w, cin, w1.shape[0], cout, st)
+    _lib.check(rc, "smos_pointnet_scatter_rows")
+    return rows
+
+
+def sparse_downsample(src, plan, wprep, bias, compact, out=None):
+    """DownSample2D(stride 2) on the occupied cells only (csrc/stem.hip): per-class MFMA GEMM + per-pixel assembly.
+    src: the compact row table of pointnet_scatter_rows (compact=True) or the dense channels-last grid [B,H,W,Cin]
+    (compact=False).  Returns the channels-last [B,Cout,H/2,W/2] view.  No host synchronisation."""
+    _require_cuda("sparse_downsample", src, bias, out, *wprep)
+    b, h, w = plan.b, plan.h, plan.w
+    cin = src.shape[-1]
+    dev = src.device
+    if src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != b * h * w * cin:
+        raise RuntimeError("sparse_downsample: src must be contiguous float32 with B*H*W rows of Cin")
+    cout = bias.shape[0]
+    per = b * (h // 2) * (w // 2)
     ys = [torch.empty((per, (taps + 1) * cout), dtype=torch.float32, device=dev) for taps in STEM_TAPS]   # worst-case capacity
     if out is None:
         out = empty_cl(b, cout, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, dev)
     y_ptrs = (ctypes.c_void_p * 4)(*[y.data_ptr() for y in ys])
     w_ptrs = (ctypes.c_void_p * 4)(*[wt.data_ptr() for wt in wprep])
-    st = _stream(bev_cl)
+    lib = _lib.load()
+    st = _stream(src)
     tag = "[%dx%dx%dx%d]" % (b, h, w, cin)
     with torch.cuda.device(dev):
-        with profiling.span("stem_mark+compact" + tag):
-            _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), st), "smos_stem_mark")
-            _lib.check(lib.smos_stem_compact(flags.data_ptr(), b, h, w, scan.data_ptr(), scan_ws.data_ptr(), scan_ws.numel(),
-                                             row_cell.data_ptr(), row_of.data_ptr(), meta.data_ptr(), st), "smos_stem_compact")
         with profiling.span("stem_gemm" + tag):
-            _lib.check(lib.smos_stem_gemm(bev_cl.data_ptr(), row_cell.data_ptr(), meta.data_ptr(), w_ptrs, y_ptrs, cin, cout, st),
-                       "smos_stem_gemm")
+            _lib.check(lib.smos_stem_gemm(src.data_ptr(), None if compact else plan.row_cell.data_ptr(), plan.meta.data_ptr(),
+                                          w_ptrs, y_ptrs, cin, cout, st), "smos_stem_gemm")
         with profiling.span("stem_epilogue" + tag):
-            _lib.check(lib.smos_stem_epilogue(y_ptrs, meta.data_ptr(), row_of.data_ptr(), bias.data_ptr(), out.data_ptr(),
+            _lib.check(lib.smos_stem_epilogue(y_ptrs, plan.meta.data_ptr(), plan.row_of.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                               _cl("sparse_downsample", out), b, h, w, cout, st), "smos_stem_epilogue")
     return out
 

@@ -154,6 +154,19 @@ def test_sparse_stem_equals_dense_downsample(model, fill):
     assert scale > 0
     assert (got - want).abs().max().item() <= 1e-5 * scale
     assert ((got > 0) == (want > 0)).float().mean().item() > 0.9999
+    # the engine's own route: the point MLP scatters into compact rows, the dense grid is never built
+    plan = ops.stem_plan(coord, h, w)
+    rows = ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)
+    n_rows = int(plan.meta[11])
+    row_of = plan.row_of.long()
+    occupied = row_of >= 0
+    assert int(occupied.sum()) == n_rows == int(plan.meta[:4].sum())
+    dense_rows = bev_cl.view(b * h * w, -1)
+    assert torch.equal(rows[row_of[occupied]], dense_rows[occupied])          # same maxima, bit for bit
+    assert not bool(dense_rows[~occupied].any())                              # and nothing outside the marked cells
+    with torch.no_grad():
+        got2 = ops.sparse_downsample(rows, plan, eng.stem_w, eng.header_bev[0].bias, compact=True)
+    assert torch.equal(got2, got)
 
 
 def test_engine_is_dropped_when_weights_change(model):

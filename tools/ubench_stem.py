@@ -27,3 +27,12 @@ def timeit(fn, n=20, warm=3):
 with torch.no_grad(), eng._conv_flags():
     print("dense block     %.3f ms" % timeit(lambda: eng._block_cl(bev_cl.permute(0, 3, 1, 2), eng.header_bev[0])))
     print("sparse (total)  %.3f ms" % timeit(lambda: eng._stem_sparse_cl(bev_cl, coord)))
+    t = lambda fn: timeit(fn)
+    print("dense scatter (fill + kernel)   %.3f ms" % t(lambda: ops.pointnet_scatter(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], bev_cl, zero_fill=True)))
+    print("plan (mark + compact)           %.3f ms" % t(lambda: ops.stem_plan(coord, 512, 512)))
+    plan = ops.stem_plan(coord, 512, 512)
+    print("compact scatter (fill + kernel) %.3f ms" % t(lambda: ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)))
+    rows = ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)
+    print("sparse downsample, dense src    %.3f ms" % t(lambda: ops.sparse_downsample(bev_cl, plan, eng.stem_w, eng.header_bev[0].bias, compact=False)))
+    print("sparse downsample, compact src  %.3f ms" % t(lambda: ops.sparse_downsample(rows, plan, eng.stem_w, eng.header_bev[0].bias, compact=True)))
+    print("rows", plan.meta.tolist())
