@@ -228,6 +228,17 @@ int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* met
                    int64_t Cin, int64_t Cout, smos_stream_t stream);
 int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
                        int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream);
+/* CatFusion + PredBranch (networks/backbone.py:387-413, 188-196): rows [B*N, K1] (row pitch in floats) ->
+ * 1x1 K1->M1 + ReLU -> 1x1 M1->M2 + ReLU -> 1x1 M2->M3 + bias, out [B, M3, N]; one kernel, intermediates in registers
+ * (csrc/point_head.hip).  Built for 192 -> 96 -> 64 -> M3 <= 32.  wprep: smos_point_head_weight_floats() floats =
+ * the three weight matrices in MFMA operand order followed by the biases (b3 padded to 32):
+ *   A1[(mt*96 + s)*64 + lane] = W1[mt*32 + (lane&31)][(lane>>5)*96 + s]
+ *   A2[(mt*48 + s)*64 + lane] = W2[mt*32 + (lane&31)][ch(s, lane>>5)],  A3[s*64 + lane] = W3[lane&31][ch(s, lane>>5)] (0 beyond M3)
+ *   with ch(s, h) = 32 (s >> 4) + 8 ((s & 15) >> 2) + 4 h + (s & 3)   (the accumulator order of the previous layer). */
+int64_t smos_point_head_weight_floats(void);
+int smos_point_head(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N, int64_t K1,
+                    int64_t M1, int64_t M2, int64_t M3, smos_stream_t stream);
+
 /* smos_pointnet_scatter with a COMPACT target: rows [n_rows, T*cout] (zero-filled by smos_stem_zero_rows) instead of
  * the dense [B,H,W,T*cout] grid; the features of cell (b, y, x) go to row row_of[b][y][x] (smos_stem_compact). */
 int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "smos_stem_epilogue": [ctypes.POINTER(vp), vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_pointnet_scatter_rows": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "smos_stem_zero_rows": [vp, vp, i64, vp],
+    "smos_point_head_weight_floats": [],
+    "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],
@@ -81,6 +83,7 @@ def load():
         fn.restype = ctypes.c_int
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
     lib.smos_stem_scan_bytes.restype = ctypes.c_int64
+    lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p
     _lib = lib

@@ -120,6 +120,15 @@ class InferenceEngine:
             rp = net.refine.bf_pred_layer.pred_layer[0]
             self.refine = (_fold(rm[0].weight, None, rm[1]), _fold(rm[3].weight, None, rm[4]),
                            (rp.weight.detach().contiguous(), rp.bias.detach().contiguous()))
+        # fused point head (csrc/point_head.hip) when the head has the reference's 192 -> 96 -> 64 -> 3 shape
+        self.fused_head = os.environ.get("SMOS_FUSED_HEAD", "1") != "0"
+        self.head_w = self.refine_w = None
+        try:
+            self.head_w = ops.point_head_prepare(self.post1, self.post2, self.pred)
+            if self.refine is not None:
+                self.refine_w = ops.point_head_prepare(*self.refine)
+        except RuntimeError:
+            self.head_w = self.refine_w = None
         if layout == "cl":
             for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
                 for p in blocks:
@@ -204,14 +213,16 @@ class InferenceEngine:
         bs, n = fuse.shape[0], fuse.shape[1]
         rows = fuse.view(bs * n, -1)
 
-        def head(l1, l2, pr):
+        def head(l1, l2, pr, fused):
+            if self.fused_head and fused is not None and fuse.stride(1) % 4 == 0:
+                return ops.point_head(fuse, fused[0], fused[1]).unsqueeze(-1)
             z = self._linear_relu(self._linear_relu(rows, l1), l2)
             out = torch.addmm(pr[1], z, pr[0].view(pr[0].shape[0], -1).t())
             return out.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
 
-        pred = head(self.post1, self.post2, self.pred)
+        pred = head(self.post1, self.post2, self.pred, self.head_w)
         if self.refine is not None:
-            return pred, head(*self.refine), aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+            return pred, head(*self.refine, self.refine_w), aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
         return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
 
     def _block_ws(self, p, n_floats):

@@ -376,6 +376,50 @@ def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None, zero_fill=F
     return bev
 
 
+def point_head_prepare(l1, l2, l3):
+    """(W1 [96,192(,1,1)], b1), (W2 [64,96], b2), (W3 [M3,64], b3) -> the flat weight block smos_point_head expects."""
+    w1, b1 = l1[0].reshape(l1[0].shape[0], -1).float(), l1[1].float()
+    w2, b2 = l2[0].reshape(l2[0].shape[0], -1).float(), l2[1].float()
+    w3, b3 = l3[0].reshape(l3[0].shape[0], -1).float(), l3[1].float()
+    if tuple(w1.shape) != (96, 192) or tuple(w2.shape) != (64, 96) or w3.shape[1] != 64 or w3.shape[0] > 32:
+        raise RuntimeError("point_head_prepare: expected 192 -> 96 -> 64 -> (<=32), got %s %s %s" % (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape)))
+    dev = w1.device
+    lane = torch.arange(64, device=dev)
+    m, h = lane & 31, lane >> 5
+    a1 = w1.view(3, 32, 2, 96).permute(0, 3, 2, 1).reshape(3, 96, 64)                     # (mt, s, h*32 + m)
+
+    def acc_order(n_steps):                                                               # ch(s, h) for s < n_steps
+        s = torch.arange(n_steps, device=dev)[:, None]
+        return 32 * (s >> 4) + 8 * ((s & 15) >> 2) + 4 * h[None, :] + (s & 3)            # [n_steps, 64]
+    ch2 = acc_order(48)
+    a2 = torch.stack([w2[mt * 32 + m[None, :].expand(48, 64), ch2] for mt in range(2)])  # (mt, s, lane)
+    w3p = torch.zeros((32, 64), device=dev)
+    w3p[:w3.shape[0]] = w3
+    a3 = w3p[m[None, :].expand(32, 64), acc_order(32)]
+    b3p = torch.zeros(32, device=dev)
+    b3p[:b3.shape[0]] = b3
+    flat = torch.cat([a1.reshape(-1), a2.reshape(-1), a3.reshape(-1), b1, b2, b3p]).contiguous()
+    if flat.numel() != int(_lib.load().smos_point_head_weight_floats()):
+        raise RuntimeError("point_head_prepare: weight block has %d floats" % flat.numel())
+    return flat, int(w3.shape[0])
+
+
+def point_head(rows, wprep, m3, out=None):
+    """rows [B, N, >=192] float32 (row stride a multiple of 4 floats) -> logits [B, m3, N]."""
+    _require_cuda("point_head", rows, wprep, out)
+    if rows.dtype != torch.float32 or rows.dim() != 3 or rows.stride(2) != 1 or rows.stride(0) != rows.shape[1] * rows.stride(1):
+        raise RuntimeError("point_head: rows must be a float32 [B, N, C] tensor with dense point rows")
+    b, n = rows.shape[0], rows.shape[1]
+    if out is None:
+        out = torch.empty((b, m3, n), dtype=torch.float32, device=rows.device)
+    lib = _lib.load()
+    with torch.cuda.device(rows.device), profiling.span("point_head[%dx%d]" % (b, n)):
+        rc = lib.smos_point_head(rows.data_ptr(), rows.stride(1), wprep.data_ptr(), out.data_ptr(), b, n, 192, 96, 64, m3,
+                                 _stream(rows))
+    _lib.check(rc, "smos_point_head")
+    return out
+
+
 STEM_TAPS = (1, 2, 2, 4)      # 3x3 taps that reach an output pixel under stride 2, per parity class (y&1)*2 + (x&1)
 
 

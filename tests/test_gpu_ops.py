@@ -269,6 +269,26 @@ def test_pointnet_scatter_against_unfused_ops(n):
     assert (rows[:, :, :64] == -7.0).all() and (rows[:, :, 128:] == -7.0).all()
 
 
+@pytest.mark.parametrize("b,n,m3", [(2, 5000 + 13, 3), (1, 64, 3), (3, 1000, 20)])
+def test_point_head_against_float64_reference(b, n, m3):
+    """CatFusion + PredBranch as one kernel (MFMA chain, intermediates in registers) vs the three 1x1 layers in float64.
+    fp32 fma chains in a different order than any GEMM library: 2e-5 of the output range."""
+    gen = torch.Generator(device="cpu").manual_seed(41)
+    rows = torch.randn((b, n, 200), generator=gen).to(DEV)[:, :, :192]                       # pitch 200 floats
+    l1 = ((torch.randn((96, 192, 1, 1), generator=gen) * 0.1).to(DEV), (torch.randn(96, generator=gen) * 0.2).to(DEV))
+    l2 = ((torch.randn((64, 96, 1, 1), generator=gen) * 0.15).to(DEV), (torch.randn(64, generator=gen) * 0.2).to(DEV))
+    l3 = ((torch.randn((m3, 64, 1, 1), generator=gen) * 0.2).to(DEV), torch.randn(m3, generator=gen).to(DEV))
+    wprep, got_m3 = ops.point_head_prepare(l1, l2, l3)
+    assert got_m3 == m3
+    out = ops.point_head(rows, wprep, m3)
+    x = rows.double().reshape(b * n, 192)
+    z = torch.relu(x @ l1[0].double().view(96, 192).t() + l1[1].double())
+    z = torch.relu(z @ l2[0].double().view(64, 96).t() + l2[1].double())
+    want = (z @ l3[0].double().view(m3, 64).t() + l3[1].double()).view(b, n, m3).permute(0, 2, 1)
+    assert out.shape == want.shape
+    assert (out.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def test_pointnet_scatter_run_boundaries_at_cell_zero():
     """Regression: cell 0 is a legal cell.  Run ends are found with a lane shuffle; evaluated under a partial exec
     mask a lane reading a masked-off neighbour gets 0, which made a point of cell 0 at position 30 of a 32-point tile
