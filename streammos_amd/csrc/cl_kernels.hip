@@ -224,6 +224,15 @@ __device__ __forceinline__ float pix_cl(float c, float s, int size) {
   return __fmul_rn(__fdiv_rn(__fadd_rn(gn, 1.0f), 2.0f), sm1);
 }
 
+// value of lane j of the caller's group.  kC = 64: the group is the wave and j is wave-uniform, so a scalar lane read
+// (v_readlane, result in an SGPR) replaces the LDS shuffle: 0.082 -> 0.070 ms per launch.  kC = 32 (two groups per wave)
+// keeps the shuffle: two lane reads + a select measured slower (0.067 vs 0.045 ms).
+template <int kC>
+__device__ __forceinline__ int group_read(int v, int j) {
+  if (kC == kWave) return __builtin_amdgcn_readlane(v, j);
+  return __shfl(v, j, kC);
+}
+
 template <int kC>
 __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
   constexpr int kGroups = kBlock / kC;
@@ -267,23 +276,43 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
     const int n_valid = min(kC, a.N - n0);
     int cur = -1;
     float best = 0.0f;
-    for (int j = 0; j < n_valid; ++j) {
-      float v = 0.0f;
+    // fixed trip count, four points per iteration: the 16 row loads of a group are issued before the first use (the
+    // loop used to be one dependent shuffle -> load -> fma -> store chain per point).  An absent tap reads row 0 and is
+    // discarded by the select, so the value is exactly the sum over the valid taps, in tap order, as before.
+    constexpr int kU = 4;
+    for (int j0 = 0; j0 < kC; j0 += kU) {
+      float g[kU][4], w[kU][4];
+      int o[kU][4], c[kU];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int o = __shfl(off[k], j, kC);
-        const float w = __shfl(wt[k], j, kC);
-        if (o >= 0) v += gb[(int64_t)o * a.gp] * w;
-      }
-      if (pb) pb[(int64_t)j * a.po_n] = v;
-      if (ob) {
-        const int c = __shfl(cell, j, kC);
-        if (c != cur) {
-          if (cur >= 0 && best > 0.0f) atomicMax(reinterpret_cast<int*>(ob + (int64_t)cur * a.op), __float_as_int(best));
-          cur = c;
-          best = 0.0f;
+      for (int u = 0; u < kU; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[u][k] = group_read<kC>(off[k], j0 + u);
+          w[u][k] = __int_as_float(group_read<kC>(__float_as_int(wt[k]), j0 + u));
         }
-        best = fmaxf(best, v);
+        c[u] = group_read<kC>(cell, j0 + u);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[u][k] = gb[(int64_t)max(o[u][k], 0) * a.gp];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int j = j0 + u;
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v = o[u][k] >= 0 ? v + g[u][k] * w[u][k] : v;
+        if (j < n_valid) {
+          if (pb) pb[(int64_t)j * a.po_n] = v;
+          if (ob) {
+            if (c[u] != cur) {
+              if (cur >= 0 && best > 0.0f) atomicMax(reinterpret_cast<int*>(ob + (int64_t)cur * a.op), __float_as_int(best));
+              cur = c[u];
+              best = 0.0f;
+            }
+            best = fmaxf(best, v);
+          }
+        }
       }
     }
     if (ob && cur >= 0 && best > 0.0f) atomicMax(reinterpret_cast<int*>(ob + (int64_t)cur * a.op), __float_as_int(best));
