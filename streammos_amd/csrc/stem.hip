@@ -162,28 +162,33 @@ __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
     const int wo = (int)(o % a.Wo);
     const int64_t t = o / a.Wo;
     const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+    // all nine row ids first, then all eighteen loads (an empty or out-of-range tap reads row 0 of its class and is
+    // discarded by the selects), then the sums in fixed tap order
+    int rid[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int y = 2 * ho - 1 + t9 / 3, x = 2 * wo - 1 + t9 % 3;
+      const bool inb = y >= 0 && y < a.H && x >= 0 && x < a.W;
+      rid[t9] = inb ? a.row_of[((int64_t)b * a.H + y) * a.W + x] : -2;     // -1: empty cell, -2: outside the grid
+    }
+    float va[9], vq[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int ky = t9 / 3, kx = t9 % 3;
+      // a cell reached through an even ky has odd y, i.e. belongs to a class with two kernel rows (slots ky / 2)
+      const int ey = (ky & 1) ^ 1, ex = (kx & 1) ^ 1;
+      const int cls = ey * 2 + ex, taps = (1 + ey) * (1 + ex);
+      const int slot = (ey ? ky >> 1 : 0) * (1 + ex) + (ex ? kx >> 1 : 0);
+      const float* row = a.y[cls] + (int64_t)max(rid[t9] - start[cls], 0) * ((taps + 1) * kC);
+      va[t9] = row[slot * kC + c];
+      vq[t9] = row[taps * kC + c];
+    }
     float acc = 0.0f, qmax = -INFINITY;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int y = 2 * ho - 1 + ky;
-      if (y < 0 || y >= a.H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int x = 2 * wo - 1 + kx;
-        if (x < 0 || x >= a.W) continue;
-        const int32_t r = a.row_of[((int64_t)b * a.H + y) * a.W + x];
-        if (r < 0) {
-          qmax = fmaxf(qmax, 0.0f);      // an empty cell: both branches see zeros there
-          continue;
-        }
-        // a cell reached through an even ky has odd y, i.e. belongs to a class with two kernel rows (slots ky / 2)
-        const int ey = (ky & 1) ^ 1, ex = (kx & 1) ^ 1;
-        const int cls = ey * 2 + ex, taps = (1 + ey) * (1 + ex);
-        const int slot = (ey ? ky >> 1 : 0) * (1 + ex) + (ex ? kx >> 1 : 0);
-        const float* row = a.y[cls] + ((int64_t)r - start[cls]) * ((taps + 1) * kC);
-        acc += row[slot * kC + c];
-        qmax = fmaxf(qmax, row[taps * kC + c]);
-      }
+    for (int t9 = 0; t9 < 9; ++t9) {
+      acc = rid[t9] >= 0 ? acc + va[t9] : acc;
+      // an empty cell inside the grid contributes 0 to the pooled branch; outside the grid nothing (padding of the pool)
+      qmax = rid[t9] >= 0 ? fmaxf(qmax, vq[t9]) : (rid[t9] == -1 ? fmaxf(qmax, 0.0f) : qmax);
     }
     a.out[o * a.op + c] = fmaxf((acc + qmax) + bias, 0.0f);
   }
