@@ -82,17 +82,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kStemK = 192, kStemSteps = kStemK / 2, kStemBlock = 512;
 
 template <int kM>
-__global__ __launch_bounds__(kStemBlock) void stem_gemm(const float* __restrict__ bev, const int32_t* __restrict__ row_cell,
-                                                        const int32_t* __restrict__ meta, int cls, const float* __restrict__ wprep,
-                                                        float* __restrict__ y) {
-  extern __shared__ float lds_w[];   // [kM][96][64]
-  for (int i = threadIdx.x; i < kM * kStemSteps * 64; i += kStemBlock) lds_w[i] = wprep[i];
+__device__ __forceinline__ void stem_gemm_class(const float* __restrict__ bev, const int32_t* __restrict__ row_cell,
+                                                const int32_t* __restrict__ meta, int cls, const float* __restrict__ wprep,
+                                                float* __restrict__ y, float* lds_w, int block, int n_blocks) {
+  for (int i = threadIdx.x; i < kM * kStemSteps * 64; i += kStemBlock) lds_w[i] = wprep[i];   // [kM][96][64]
   __syncthreads();
   const int n = meta[cls], start = meta[4 + cls];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, hh = lane >> 5;
   constexpr int kWaves = kStemBlock / 64;
-  for (int tile = blockIdx.x * kWaves + wave; tile * 32 < n; tile += gridDim.x * kWaves) {
+  for (int tile = block * kWaves + wave; tile * 32 < n; tile += n_blocks * kWaves) {
     const int r = tile * 32 + col;
     const bool valid = r < n;
     // row_cell == null: bev already IS the compact row table (smos_pointnet_scatter_rows), row = start + r
@@ -137,6 +136,30 @@ __global__ __launch_bounds__(kStemBlock) void stem_gemm(const float* __restrict_
               make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
     }
   }
+}
+
+// ONE launch for the four parity classes: the blocks are split between the classes in proportion to their work
+// (equal row counts by symmetry, 2 : 3 : 3 : 5 output blocks), every block keeps its class's weights in LDS.
+struct StemGemmArgs {
+  const float* bev;
+  const int32_t* row_cell;
+  const int32_t* meta;
+  const float* wprep[4];
+  float* y[4];
+  int first_block[5];
+};
+
+__global__ __launch_bounds__(kStemBlock) void stem_gemm(StemGemmArgs a) {
+  extern __shared__ float lds_w[];
+  const int bid = blockIdx.x;
+  if (bid < a.first_block[1])
+    stem_gemm_class<2>(a.bev, a.row_cell, a.meta, 0, a.wprep[0], a.y[0], lds_w, bid - a.first_block[0], a.first_block[1] - a.first_block[0]);
+  else if (bid < a.first_block[2])
+    stem_gemm_class<3>(a.bev, a.row_cell, a.meta, 1, a.wprep[1], a.y[1], lds_w, bid - a.first_block[1], a.first_block[2] - a.first_block[1]);
+  else if (bid < a.first_block[3])
+    stem_gemm_class<3>(a.bev, a.row_cell, a.meta, 2, a.wprep[2], a.y[2], lds_w, bid - a.first_block[2], a.first_block[3] - a.first_block[2]);
+  else
+    stem_gemm_class<5>(a.bev, a.row_cell, a.meta, 3, a.wprep[3], a.y[3], lds_w, bid - a.first_block[3], a.first_block[4] - a.first_block[3]);
 }
 
 struct StemEpiArgs {
@@ -236,38 +259,41 @@ extern "C" int smos_stem_compact(const int32_t* flags, int64_t B, int64_t H, int
   return check_launch("stem_compact");
 }
 
-template <int kM>
-static void launch_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, int cls, const float* wprep, float* y,
-                             int blocks, hipStream_t s) {
-  const size_t lds = (size_t)kM * kStemSteps * 64 * sizeof(float);
-  static bool raised = false;
-  if (!raised) {   // more than the default 64 KB of dynamic LDS per block
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_gemm<kM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    raised = true;
-  }
-  hipLaunchKernelGGL((stem_gemm<kM>), dim3(blocks), dim3(kStemBlock), lds, s, bev, row_cell, meta, cls, wprep, y);
-}
-
 extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4,
                               float* const* y4, int64_t Cin, int64_t Cout, smos_stream_t stream) {
   SMOS_REQUIRE(Cin == kStemK && Cout == 32, "stem_gemm: built for 192 -> 32 channels");
   SMOS_REQUIRE(bev && meta && wprep4 && y4, "stem_gemm: null pointer");
   for (int c = 0; c < 4; ++c) SMOS_REQUIRE(wprep4[c] && y4[c], "stem_gemm: null class pointer");
+  const size_t lds = (size_t)5 * kStemSteps * 64 * sizeof(float);   // the largest class: 4 taps + the pool branch
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      set_error("stem_gemm: device query failed");
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+      set_error("stem_gemm: device setup failed");
       return SMOS_ERR_LAUNCH;
     }
     cus = prop.multiProcessorCount;
   }
-  hipStream_t s = (hipStream_t)stream;
-  launch_stem_gemm<2>(bev, row_cell, meta, 0, wprep4[0], y4[0], cus, s);
-  launch_stem_gemm<3>(bev, row_cell, meta, 1, wprep4[1], y4[1], cus, s);
-  launch_stem_gemm<3>(bev, row_cell, meta, 2, wprep4[2], y4[2], cus, s);
-  launch_stem_gemm<5>(bev, row_cell, meta, 3, wprep4[3], y4[3], cus, s);
+  StemGemmArgs a;
+  a.bev = bev; a.row_cell = row_cell; a.meta = meta;
+  for (int c = 0; c < 4; ++c) {
+    a.wprep[c] = wprep4[c];
+    a.y[c] = y4[c];
+  }
+  // one block per CU (120 KB of LDS); shares 2 : 3 : 3 : 5 of at least one block each
+  const int blocks = cus < 4 ? 4 : cus;
+  const int share[4] = {2, 3, 3, 5};
+  int at = 0;
+  for (int c = 0; c < 4; ++c) {
+    a.first_block[c] = at;
+    int nb = blocks * share[c] / 13;
+    at += nb < 1 ? 1 : nb;
+  }
+  a.first_block[4] = at;
+  hipLaunchKernelGGL(stem_gemm, dim3(at), dim3(kStemBlock), lds, (hipStream_t)stream, a);
   return check_launch("stem_gemm");
 }
 
