@@ -228,6 +228,19 @@ int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* met
                    int64_t Cin, int64_t Cout, smos_stream_t stream);
 int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
                        int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream);
+/* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
+ * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels
+ * [t*C, (t+1)*C)), computed by the caller with one GEMM.
+ *   smos_upconv_xpass  t [B, 3, Hs, Wo, C] <- sum_kx up_x(z tap (ky,kx))[X + kx - 1]   (taps leaving [0, Wo) dropped)
+ *   smos_upconv_ypass  out [B, Ho, Wo, *] (row pitch out_pitch) <- act(conv_a + bias + sum_src sum_ky up_y(t_src)[Y + ky - 1]);
+ *                      conv_a [B, Ho, Wo, *] (row pitch a_pitch) is the direct convolution of the channels that are not
+ *                      upsampled; t2 may be NULL; act 0 none, 1 ReLU, 2 LeakyReLU(0.01); interpolation with ATen's
+ *                      align_corners=True weights. */
+int smos_upconv_xpass(const float* z, float* t, int64_t B, int64_t Hs, int64_t Ws, int64_t C, int64_t Wo, smos_stream_t stream);
+int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const float* bias, const float* t1, int64_t H1, const float* t2,
+                      int64_t H2, float* out, int64_t out_pitch, int64_t B, int64_t Ho, int64_t Wo, int64_t C, int32_t act,
+                      smos_stream_t stream);
+
 /* CatFusion + PredBranch (networks/backbone.py:387-413, 188-196): rows [B*N, K1] (row pitch in floats) ->
  * 1x1 K1->M1 + ReLU -> 1x1 M1->M2 + ReLU -> 1x1 M2->M3 + bias, out [B, M3, N]; one kernel, intermediates in registers
  * (csrc/point_head.hip).  Built for 192 -> 96 -> 64 -> M3 <= 32.  wprep: smos_point_head_weight_floats() floats =

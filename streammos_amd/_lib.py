@@ -44,6 +44,8 @@ SIGNATURES = {
     "smos_stem_zero_rows": [vp, vp, i64, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
+    "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
+    "smos_upconv_ypass": [vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],

@@ -1,0 +1,140 @@
+// 3x3 convolution of a bilinearly upsampled map without upsampling it first (gfx950).
+//
+// The decoder (multi_view_encoder.py:441-453) resizes the 128-channel maps of the two coarser stages to 256 x 256
+// (F.interpolate, bilinear, align_corners=True), concatenates them with the 64-channel fine map and runs conv_1
+// (3x3, 320 -> 128): 48.3 GFLOP per sample, 37 % of all FLOPs of the network -- 80 % of them spent on
+// inputs that are interpolations of 16x / 4x smaller maps.  Channel mixing and spatial operators commute:
+//     conv3x3(up(x)) = sum_{ky,kx} shift_{ky,kx}( up( W_{ky,kx} x ) ),        W_{ky,kx}: the [Cout, Cin] matrix of one tap,
+// so the nine tap products are taken at the SOURCE resolution (one GEMM [pixels, Cin] x [Cin, 9 Cout], 16x / 4x fewer
+// pixels) and only the cheap spatial part runs at 256 x 256, separably:
+//   x pass (upconv_xpass): T[b, ky, ys, X, c]  = sum_kx  up_x( Z[b, ys, :, (3 ky + kx) C + c] )[X + kx - 1]
+//   y pass (upconv_ypass): out[b, Y, X, c]     = act( conv_a + bias + sum_src sum_ky  up_y( T_src[b, ky, :, X, c] )[Y + ky - 1] )
+// with the zero padding of the convolution applied at the upsampled resolution (taps that leave the 256 x 256 image are
+// dropped) and conv_a the ordinary convolution of the channels that are NOT upsampled.  Exact in real arithmetic;
+// in float32 it differs from the direct form by summation order only.  conv_1 falls from 48.3 to 15.7 GFLOP per sample
+// and the 320-channel concatenated input (336 MB) is never built.
+// Interpolation weights: ATen's align_corners=True formula, as in upsample_concat_cl (cl_kernels.hip).
+#include "smos_common.h"
+
+namespace smos {
+
+struct Lerp {
+  int i0, step;     // source index and 0/1 step to the second tap
+  float w0, w1;
+};
+
+__device__ __forceinline__ Lerp lerp_of(int dst, int n_src, int n_dst) {
+  const float r = n_dst > 1 ? (float)(n_src - 1) / (float)(n_dst - 1) : 0.0f;
+  const float s = r * dst;
+  Lerp l;
+  l.i0 = (int)s;
+  l.step = (l.i0 < n_src - 1) ? 1 : 0;
+  l.w1 = s - l.i0;
+  l.w0 = 1.0f - l.w1;
+  return l;
+}
+
+// z [B, Hs, Ws, 9*C] (tap-major blocks of C channels), t [B, 3, Hs, Wo, C]; one thread = 4 channels of one (b, ky, ys, X)
+__global__ __launch_bounds__(kBlock) void upconv_xpass(const float* __restrict__ z, float* __restrict__ t, int B, int Hs, int Ws,
+                                                       int C4, int Wo) {
+  const int64_t total = (int64_t)B * 3 * Hs * Wo * C4;
+  const int C = C4 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4) * 4;
+    int64_t r = i / C4;
+    const int X = (int)(r % Wo);
+    r /= Wo;
+    const int ys = (int)(r % Hs);
+    r /= Hs;
+    const int ky = (int)(r % 3), b = (int)(r / 3);
+    const float* zrow = z + (((int64_t)b * Hs + ys) * Ws) * (9 * C) + (3 * ky) * C + q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xs = X + kx - 1;
+      if (xs < 0 || xs >= Wo) continue;          // zero padding of the convolution, at the upsampled resolution
+      const Lerp l = lerp_of(xs, Ws, Wo);
+      const float* p = zrow + (int64_t)l.i0 * (9 * C) + kx * C;
+      const float4 v0 = *reinterpret_cast<const float4*>(p);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)l.step * (9 * C));
+      acc.x += l.w0 * v0.x + l.w1 * v1.x; acc.y += l.w0 * v0.y + l.w1 * v1.y;
+      acc.z += l.w0 * v0.z + l.w1 * v1.z; acc.w += l.w0 * v0.w + l.w1 * v1.w;
+    }
+    *reinterpret_cast<float4*>(t + i * 4) = acc;
+  }
+}
+
+struct YSrc {
+  const float* t;   // [B, 3, Hs, Wo, C] or null
+  int Hs;
+};
+
+// out = act(conv_a + bias + sum over the sources and ky of the y-interpolated x-pass rows); act: 0 none, 1 ReLU, 2 LeakyReLU(0.01)
+__global__ __launch_bounds__(kBlock) void upconv_ypass(const float* __restrict__ conv_a, int64_t ap, const float* __restrict__ bias,
+                                                       YSrc s1, YSrc s2, float* __restrict__ out, int64_t op, int B, int Ho, int Wo,
+                                                       int C4, int act) {
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  const int C = C4 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4) * 4;
+    int64_t r = i / C4;
+    const int X = (int)(r % Wo);
+    r /= Wo;
+    const int Y = (int)(r % Ho), b = (int)(r / Ho);
+    const int64_t pix = ((int64_t)b * Ho + Y) * Wo + X;
+    float4 acc = *reinterpret_cast<const float4*>(conv_a + pix * ap + q);
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+      const YSrc s = si == 0 ? s1 : s2;
+      if (!s.t) continue;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ysrc = Y + ky - 1;
+        if (ysrc < 0 || ysrc >= Ho) continue;
+        const Lerp l = lerp_of(ysrc, s.Hs, Ho);
+        const float* p = s.t + ((((int64_t)b * 3 + ky) * s.Hs + l.i0) * Wo + X) * C + q;
+        const float4 v0 = *reinterpret_cast<const float4*>(p);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)l.step * Wo * C);
+        acc.x += l.w0 * v0.x + l.w1 * v1.x; acc.y += l.w0 * v0.y + l.w1 * v1.y;
+        acc.z += l.w0 * v0.z + l.w1 * v1.z; acc.w += l.w0 * v0.w + l.w1 * v1.w;
+      }
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + q);
+    float4 o = make_float4(acc.x + bv.x, acc.y + bv.y, acc.z + bv.z, acc.w + bv.w);
+    if (act == 1) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    } else if (act == 2) {
+      o.x = o.x > 0.f ? o.x : 0.01f * o.x; o.y = o.y > 0.f ? o.y : 0.01f * o.y;
+      o.z = o.z > 0.f ? o.z : 0.01f * o.z; o.w = o.w > 0.f ? o.w : 0.01f * o.w;
+    }
+    *reinterpret_cast<float4*>(out + pix * op + q) = o;
+  }
+}
+
+}  // namespace smos
+
+using namespace smos;
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int smos_upconv_xpass(const float* z, float* t, int64_t B, int64_t Hs, int64_t Ws, int64_t C, int64_t Wo,
+                                 smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 4 == 0 && Wo > 0, "upconv_xpass: bad sizes (C %% 4 must be 0)");
+  SMOS_REQUIRE(z && t && aligned16(z) && aligned16(t), "upconv_xpass: null / unaligned pointer");
+  hipLaunchKernelGGL(upconv_xpass, dim3(grid_for(B * 3 * Hs * Wo * (C / 4), kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, z, t,
+                     (int)B, (int)Hs, (int)Ws, (int)(C / 4), (int)Wo);
+  return check_launch("upconv_xpass");
+}
+
+extern "C" int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const float* bias, const float* t1, int64_t H1, const float* t2,
+                                 int64_t H2, float* out, int64_t out_pitch, int64_t B, int64_t Ho, int64_t Wo, int64_t C, int32_t act,
+                                 smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 && act >= 0 && act <= 2 && a_pitch % 4 == 0 && out_pitch % 4 == 0,
+               "upconv_ypass: bad arguments");
+  SMOS_REQUIRE(conv_a && bias && out && aligned16(conv_a) && aligned16(out) && aligned16(bias) && (!t1 || (aligned16(t1) && H1 > 0)) &&
+                   (!t2 || (aligned16(t2) && H2 > 0)), "upconv_ypass: null / unaligned pointer");
+  YSrc s1{t1, (int)H1}, s2{t2, (int)H2};
+  hipLaunchKernelGGL(upconv_ypass, dim3(grid_for(B * Ho * Wo * (C / 4), kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, conv_a,
+                     a_pitch, bias, s1, s2, out, out_pitch, (int)B, (int)Ho, (int)Wo, (int)(C / 4), (int)act);
+  return check_launch("upconv_ypass");
+}

@@ -108,6 +108,13 @@ class InferenceEngine:
             off += cin[i]
         self.aux = (w.contiguous(), torch.cat([h.bias.detach() for h in heads]).contiguous(), ncls)
         self.grid2point_scale = tuple(net.bev_grid2point.scale_rate)
+        # conv_1 without the upsampled concatenation (csrc/upconv.hip): direct conv on the fine map's channels, tap GEMMs
+        # at source resolution for the two coarser maps; the aux heads likewise run before the (linear) upsampling
+        self.upconv = os.environ.get("SMOS_UPCONV", "1") != "0"
+        w1 = self.conv_1[0]
+        self.conv_1a = w1[:, :cin[0]].contiguous()
+        self.conv_1z = (ops.upconv_tap_weights(w1, cin[0], cin[0] + cin[1]), ops.upconv_tap_weights(w1, cin[0] + cin[1], sum(cin)))
+        self.aux_split = [(h.weight.detach().contiguous(), h.bias.detach().contiguous()) for h in heads]
 
         m = net.point_post.merge_layer
         self.post1 = _fold(m[0].weight, None, m[1])
@@ -135,6 +142,8 @@ class InferenceEngine:
                     for k in ("wa", "wp", "wb", "wc", "w1", "w2"):
                         if hasattr(p, k):
                             setattr(p, k, _cl_w(getattr(p, k)))
+            self.conv_1a = _cl_w(self.conv_1a)
+            self.aux_split = [(_cl_w(w), b) for w, b in self.aux_split]
             self.conv_1 = (_cl_w(self.conv_1[0]), self.conv_1[1])
             self.conv_2 = (_cl_w(self.conv_2[0]), self.conv_2[1])
             self.aux = (_cl_w(self.aux[0]), self.aux[1], self.aux[2])
@@ -212,6 +221,7 @@ class InferenceEngine:
         """CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3 (and the stage-2 refine head)."""
         bs, n = fuse.shape[0], fuse.shape[1]
         rows = fuse.view(bs * n, -1)
+        a3 = tuple(aux) if isinstance(aux, (tuple, list)) else (aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:])
 
         def head(l1, l2, pr, fused):
             if self.fused_head and fused is not None and fuse.stride(1) % 4 == 0:
@@ -222,8 +232,8 @@ class InferenceEngine:
 
         pred = head(self.post1, self.post2, self.pred, self.head_w)
         if self.refine is not None:
-            return pred, head(*self.refine, self.refine_w), aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
-        return pred, aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:], x2
+            return (pred, head(*self.refine, self.refine_w)) + a3 + (x2,)
+        return (pred,) + a3 + (x2,)
 
     def _block_ws(self, p, n_floats):
         """Scratch of one channel-attention block.  Every block owns its buffer: blocks of different pipeline stages run
@@ -405,13 +415,22 @@ class InferenceEngine:
 
     def _decode_cl(self, enc, x2):
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
-        dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
-        y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
-        ops.bias_act_cl(y, self.conv_1[1], LEAKY, out=y)
+        k = self.aux[2]
+        if self.upconv:
+            y = ops.upconv3x3(F.conv2d(x0cat, self.conv_1a, None, 1, 1), self.conv_1[1],
+                              [(x1cat, self.conv_1z[0]), (x2, self.conv_1z[1])], LEAKY)
+            size = tuple(x0cat.shape[2:])
+            aux = [F.conv2d(x0cat, *self.aux_split[0])]
+            for src, (w, b) in ((x1cat, self.aux_split[1]), (x2, self.aux_split[2])):
+                # a 1x1 convolution commutes with the (linear, weights summing to 1) bilinear resize
+                aux.append(F.interpolate(F.conv2d(src, w, b), size=size, mode="bilinear", align_corners=True))
+        else:
+            dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
+            y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
+            ops.bias_act_cl(y, self.conv_1[1], LEAKY, out=y)
+            aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
         bev_feat = F.conv2d(y, self.conv_2[0], None, 1, 1)
         ops.bias_act_cl(bev_feat, self.conv_2[1], LEAKY, out=bev_feat)
-        aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
-        k = self.aux[2]
         ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
         return self._point_heads(fuse, aux, k, x2)
 

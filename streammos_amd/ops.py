@@ -420,6 +420,41 @@ def point_head(rows, wprep, m3, out=None):
     return out
 
 
+def upconv_tap_weights(w, c0, c1):
+    """w [Cout, Cin, 3, 3] -> [9*Cout, c1-c0]: the per-tap matrices of input channels [c0, c1), tap-major (t = 3 ky + kx)."""
+    cout = w.shape[0]
+    return w[:, c0:c1].permute(2, 3, 0, 1).reshape(9 * cout, c1 - c0).float().contiguous()
+
+
+def upconv3x3(conv_a, bias, sources, act, out=None):
+    """act(conv_a + bias + sum over sources of conv3x3(bilinear_up(x_src), W_src)) without upsampling (csrc/upconv.hip).
+    conv_a: channels-last [B,C,Ho,Wo] view (direct conv of the non-upsampled channels); sources: list of (x_cl
+    [B,Cin,Hs,Ws] channels-last view with dense rows, tap weights from upconv_tap_weights) -- one or two."""
+    _require_cuda("upconv3x3", conv_a, bias, out)
+    b, c, ho, wo = conv_a.shape
+    if out is None:
+        out = conv_a
+    lib = _lib.load()
+    st = _stream(conv_a)
+    ts = []
+    with torch.cuda.device(conv_a.device):
+        for x, wt in sources:
+            hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
+            rows = x.permute(0, 2, 3, 1).reshape(b * hs * ws, cin)         # no copy for a dense channels-last map
+            z = torch.mm(rows, wt.t())                                      # [B*Hs*Ws, 9*C]: the nine tap products
+            t = torch.empty((b, 3, hs, wo, c), dtype=torch.float32, device=conv_a.device)
+            with profiling.span("upconv_xpass[%dx%dx%dx%d->%d]" % (b, hs, ws, c, wo)):
+                _lib.check(lib.smos_upconv_xpass(z.data_ptr(), t.data_ptr(), b, hs, ws, c, wo, st), "smos_upconv_xpass")
+            ts.append((t, hs))
+        t1, h1 = ts[0]
+        t2, h2 = ts[1] if len(ts) > 1 else (None, 0)
+        with profiling.span("upconv_ypass[%dx%dx%dx%d]" % (b, ho, wo, c)):
+            _lib.check(lib.smos_upconv_ypass(conv_a.data_ptr(), _cl("upconv3x3", conv_a), bias.data_ptr(), t1.data_ptr(), h1,
+                                             t2.data_ptr() if t2 is not None else None, h2, out.data_ptr(), _cl("upconv3x3", out),
+                                             b, ho, wo, c, int(act), st), "smos_upconv_ypass")
+    return out
+
+
 STEM_TAPS = (1, 2, 2, 4)      # 3x3 taps that reach an output pixel under stride 2, per parity class (y&1)*2 + (x&1)
 
 

@@ -289,6 +289,28 @@ def test_point_head_against_float64_reference(b, n, m3):
     assert (out.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("ho,wo,sizes", [(64, 48, ((32, 24), (16, 12))), (40, 40, ((20, 20),)), (33, 47, ((9, 13), (5, 6)))])
+def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes):
+    """conv3x3(cat(x0, up(x1), up(x2))) + bias + LeakyReLU computed as direct conv on x0 + tap GEMMs at source resolution
+    + separable interpolation passes, against the direct form in float64.  Odd sizes exercise the align_corners ratios
+    and the image borders (taps leaving the upsampled image must be dropped, not clamped)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(43)
+    b, c0, cs, cout = 2, 8, 16, 32
+    x0 = torch.randn((b, c0, ho, wo), generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    xs = [torch.randn((b, cs) + hw, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last) for hw in sizes]
+    cin = c0 + cs * len(xs)
+    w = (torch.randn((cout, cin, 3, 3), generator=gen) * 0.1).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    ups = [F.interpolate(x.double(), size=(ho, wo), mode="bilinear", align_corners=True) for x in xs]
+    want = F.leaky_relu(F.conv2d(torch.cat([x0.double()] + ups, 1), w.double(), bias.double(), 1, 1), 0.01)
+    conv_a = F.conv2d(x0, w[:, :c0].contiguous(memory_format=torch.channels_last), None, 1, 1)
+    assert conv_a.is_contiguous(memory_format=torch.channels_last)
+    srcs = [(x, ops.upconv_tap_weights(w, c0 + i * cs, c0 + (i + 1) * cs)) for i, x in enumerate(xs)]
+    got = ops.upconv3x3(conv_a, bias, srcs, 2)
+    assert (got.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def test_pointnet_scatter_run_boundaries_at_cell_zero():
     """Regression: cell 0 is a legal cell.  Run ends are found with a lane shuffle; evaluated under a partial exec
     mask a lane reading a masked-off neighbour gets 0, which made a point of cell 0 at position 30 of a 32-point tile
