@@ -279,8 +279,9 @@ def main():
             "path_compute_roofline": {"bound": "mfma", "achieved": round(value / world * ALG_TFLOP_PER_SCAN, 1),
                                       "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(value / world * ALG_TFLOP_PER_SCAN / FP32_PEAK_TFLOPS, 4),
-                                      "note": "the path computes in fp32 like the reference: 0.53 TFLOP/scan against the fp32 "
-                                              "MFMA/vector peak is the ceiling that binds first (296 scans/s), not HBM"},
+                                      "note": "dense-equivalent rate: the reference's 0.53 TFLOP/scan (fp32) x scans/s against the fp32 "
+                                              "MFMA/vector peak; the engine executes ~0.37 TFLOP of them (sparse first stage, "
+                                              "conv_1 as tap GEMMs at source resolution), so this is not a hard ceiling"},
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
