@@ -18,6 +18,17 @@ for r in step:
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     agg[r["Kernel_Name"][:120]][0] += 1
     agg[r["Kernel_Name"][:120]][1] += d
-print("# busy %.3f ms" % (sum(v[1] for v in agg.values()) / 1e6))
+print("# kernel time summed over all streams %.3f ms" % (sum(v[1] for v in agg.values()) / 1e6))
+# time during which at least one / at least two kernels run (the two pipeline stages overlap)
+ev = sorted([(int(r["Start_Timestamp"]), 1) for r in step] + [(int(r["End_Timestamp"]), -1) for r in step])
+depth, last, any_busy, two_busy = 0, t0, 0, 0
+for ts, d in ev:
+    if depth >= 1:
+        any_busy += ts - last
+    if depth >= 2:
+        two_busy += ts - last
+    depth += d
+    last = ts
+print("# at least one kernel running %.3f ms (idle %.3f ms), at least two %.3f ms" % (any_busy / 1e6, (t1 - t0 - any_busy) / 1e6, two_busy / 1e6))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%9.1f us  x%3d  %s" % (v[1] / 1e3, v[0], k))

@@ -292,6 +292,13 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
         }
         c[u] = group_read<kC>(cell, j0 + u);
       }
+      // scatter-only launch: a group of points without a target cell (the padding tail of a scan) needs no gather
+      if (!pb) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) any |= c[u] >= 0;
+        if (!any) continue;
+      }
 #pragma unroll
       for (int u = 0; u < kU; ++u)
 #pragma unroll

@@ -180,6 +180,14 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     // a lane that reads a masked-off lane gets 0 -- indistinguishable from cell 0
     const int cell_after = __shfl_down(cell, 1);
     const uint32_t tails = (uint32_t)__ballot(hh == 0 && (col == kNt - 1 || cell != cell_after));
+    // a tile none of whose points falls into the grid (the padding tail of a scan: 25-40 % of the rows) produces nothing
+    // unless its point rows are wanted (t == 0): skip the matrix work, keep the software pipeline moving
+    if (!(a.pts_out && t == 0) && __ballot(cell >= 0) == 0) {
+      const int cell_skip = cell_of(nxt, nt + nt_step);
+      cur = nxt;
+      cell = cell_skip;
+      continue;
+    }
 
     f32x16 c1[2];
 #pragma unroll
