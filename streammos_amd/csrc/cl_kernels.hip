@@ -299,10 +299,23 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
         for (int u = 0; u < kU; ++u) any |= c[u] >= 0;
         if (!any) continue;
       }
+      // a group whose points all lie outside the source map (padding again) gathers nothing: its rows are zeros
+      bool any_tap = false;
 #pragma unroll
       for (int u = 0; u < kU; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[u][k] = gb[(int64_t)max(o[u][k], 0) * a.gp];
+        for (int k = 0; k < 4; ++k) any_tap |= o[u][k] >= 0;
+      if (any_tap) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[u][k] = gb[(int64_t)max(o[u][k], 0) * a.gp];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[u][k] = 0.0f;
+      }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int j = j0 + u;
