@@ -63,6 +63,9 @@ def algorithmic_bytes(label):
     if name == "msda_fwd":
         n, lq, m, d = (int(v) for v in dims.split("x"))
         return 4 * (n * lq * m * d * 2 + n * lq * m * 4 * 3)
+    if name == "point_head":
+        b, n = (int(v) for v in dims.split("x"))
+        return 4 * b * n * (192 + 3)
     if name in ("stem_gemm", "stem_epilogue", "stem_mark+compact"):
         # sparse DownSample2D 192 -> 32, stride 2: the dense op it replaces reads the grid once and writes the half-
         # resolution map; the three spans of the sparse form share that figure (gemm: grid in; epilogue: map out)
@@ -72,6 +75,16 @@ def algorithmic_bytes(label):
         if name == "stem_epilogue":
             return 4 * b * (h // 2) * (w // 2) * 32
         return 4 * b * h * w
+    return 0
+
+
+def algorithmic_flops(label):
+    """FLOPs of a launch whose time is set by the matrix cores rather than by HBM (0 = not such a kernel)."""
+    name, dims = label.split("[", 1)
+    dims = dims.rstrip("]")
+    if name == "point_head":
+        b, n = (int(v) for v in dims.split("x"))
+        return 2 * b * n * (192 * 96 + 96 * 64 + 64 * 3)
     return 0
 
 
@@ -236,10 +249,32 @@ def main():
         if dominant and dominant in timed:
             calls, total_ms, mean_ms = timed[dominant]
             ab = algorithmic_bytes(dominant)
-            achieved = ab / (mean_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
-                    "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(mean_ms, 4), "launches": calls}
+            af = algorithmic_flops(dominant)
+            if af and af / (FP32_PEAK_TFLOPS * 1e12) > ab / (HBM_PEAK_GBS * 1e9):
+                # the matrix-core time of the launch exceeds its HBM time: an MFMA-bound kernel (the fused point head)
+                achieved = af / (mean_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dominant),
+                        "algorithmic_flops_per_launch": af, "algorithmic_bytes_per_launch": ab,
+                        "avg_launch_ms": round(mean_ms, 4), "launches": calls}
+            else:
+                achieved = ab / (mean_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(mean_ms, 4), "launches": calls}
+        if roof and dominant.startswith("point_head") and getattr(model, "_engine", None) is not None:
+            # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
+            from streammos_amd import ops as _ops
+            eng, d0 = model._engine, dev_frames[0][0]
+            bs, n = d0["pcds_xyzi"].shape[0], d0["pcds_xyzi"].shape[3]
+            rows = torch.randn((bs, n, 192), dtype=torch.float32, device=device)
+            torch.cuda.synchronize()
+            with profiling.kernel_timer(only=dominant) as kt_iso:
+                for _ in range(20):
+                    _ops.point_head(rows, eng.head_w[0], eng.head_w[1])
+            iso = kt_iso.summary()[dominant][2]
+            roof["isolated_launch_ms"] = round(iso, 4)
+            roof["isolated_frac"] = round(roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
         if roof and dominant.startswith("pointnet_scatter") and getattr(model, "_engine", None) is not None:
             # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
             from streammos_amd import ops as _ops

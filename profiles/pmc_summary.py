@@ -31,6 +31,16 @@ def per_label(path, counter):
             out["pointnet_scatter[4x3x160000->512x512]:kernel"].append(v)
         elif "FillFunctor" in k and r["Grid_Size"] == "50331648":
             out["pointnet_scatter[4x3x160000->512x512]:zero_fill"].append(v)
+        elif "stem_zero_rows" in k:                       # the zero fill of the compact row table (inside the span)
+            out["pointnet_scatter[4x3x160000->512x512]:zero_fill"].append(v)
+        elif "point_head" in k:
+            out["point_head[4x160000]:kernel"].append(v)
+        elif "stem_gemm" in k:
+            out["stem_gemm[4x512x512x192]:kernel"].append(v)
+        elif "stem_epilogue" in k:
+            out["stem_epilogue[4x512x512x192]:kernel"].append(v)
+        elif "upconv_ypass" in k:
+            out["upconv_ypass[4x256x256x128]:kernel"].append(v)
         elif "gather_scatter_cl" in k:
             out[GS_ORDER[gs % 5]].append(v)
             gs += 1
