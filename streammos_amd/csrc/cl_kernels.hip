@@ -111,12 +111,23 @@ __global__ __launch_bounds__(kBlock) void gate_mlp(const float* __restrict__ par
                                                    const float* __restrict__ w2, const float* __restrict__ b2, int C, int Cr,
                                                    int64_t HW, float* __restrict__ gate) {
   __shared__ float mean[256];
+  __shared__ float part_sum[kBlock];
   __shared__ float hidden[64];
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  {
+    // the chunk sums of a channel are added by 256 / C threads in a fixed interleaved order (deterministic), instead of
+    // one thread walking all chunks serially (that was 15 us of dependent loads on the block's critical path)
+    const int parts = kBlock / C, c = threadIdx.x % C, part = threadIdx.x / C;
     float s = 0.0f;
-    for (int k = 0; k < chunks; ++k) s += partial[((int64_t)b * chunks + k) * C + c];
-    mean[c] = s / (float)HW + bias[c];
+    if (part < parts)
+      for (int k = part; k < chunks; k += parts) s += partial[((int64_t)b * chunks + k) * C + c];
+    part_sum[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float t = 0.0f;
+      for (int q = 0; q < parts; ++q) t += part_sum[q * C + threadIdx.x];
+      mean[threadIdx.x] = t / (float)HW + bias[threadIdx.x];
+    }
   }
   __syncthreads();
   for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
