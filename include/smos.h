@@ -228,6 +228,18 @@ int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* met
                    int64_t Cin, int64_t Cout, smos_stream_t stream);
 int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
                        int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream);
+/* The sampler of smos_msda_fwd fed by the raw query projection of a DeformAttnLayer (multi_view_encoder.py:300-316):
+ * qp [N, H*W, M*P*2 + M*P] = per token the sampling offsets (x, y per head and point) followed by the attention logits;
+ * single level H x W, queries on the same H x W lattice with the cell centres as reference points.  Folds softmax over the
+ * P logits, off / (W, H) and + reference point into the kernel.  value [N, H*W, M, D], out [N, H*W, M*D]; D == 32, P <= 8. */
+int smos_msda_fwd_qp(const float* value, const float* qp, float* out, int64_t N, int64_t H, int64_t W, int64_t M, int64_t D,
+                     int64_t P, smos_stream_t stream);
+
+/* out = LayerNorm(x + res) over rows of C floats (res may be NULL): the residual + norm steps of a DeformAttnLayer
+ * (multi_view_encoder.py:314-320).  C in {64, 128, 256, 512}; biased variance, eps inside the square root (torch). */
+int smos_add_layer_norm(const float* x, const float* res, const float* gamma, const float* beta, float* out, int64_t rows,
+                        int64_t C, float eps, smos_stream_t stream);
+
 /* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
  * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels
  * [t*C, (t+1)*C)), computed by the caller with one GEMM.

@@ -44,6 +44,8 @@ SIGNATURES = {
     "smos_stem_zero_rows": [vp, vp, i64, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
+    "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
+    "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_upconv_ypass": [vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],

@@ -350,3 +350,67 @@ extern "C" int smos_upsample_concat(const float* const* src, const int64_t* src_
                      (int)Wo);
   return check_launch("upsample_concat");
 }
+
+// ---------------------------------------------------------------------------------------------
+// out = LayerNorm(x + res) over the last dimension (DeformAttnLayer, multi_view_encoder.py:314-320: the two residual
+// + norm steps of a layer), one wave per token row, C a multiple of 64 up to 512.  Two-pass moments in registers.
+// ---------------------------------------------------------------------------------------------
+namespace smos {
+
+template <int kPer>
+__global__ __launch_bounds__(kBlock) void add_layer_norm(const float* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ out, int64_t rows, float eps) {
+  constexpr int C = kPer * kWave;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+  float g[kPer], bt[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    g[k] = gamma[k * kWave + lane];
+    bt[k] = beta[k * kWave + lane];
+  }
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    float v[kPer];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      v[k] = x[r * C + k * kWave + lane] + (res ? res[r * C + k * kWave + lane] : 0.0f);
+      s += v[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) q += (v[k] - mean) * (v[k] - mean);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) out[r * C + k * kWave + lane] = (v[k] - mean) * rstd * g[k] + bt[k];
+  }
+}
+
+}  // namespace smos
+
+extern "C" int smos_add_layer_norm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
+                                   int64_t rows, int64_t C, float eps, smos_stream_t stream) {
+  using namespace smos;
+  SMOS_REQUIRE(rows >= 0 && C > 0 && C % kWave == 0 && C <= 512, "add_layer_norm: C must be a multiple of 64 up to 512");
+  if (rows == 0) return SMOS_OK;
+  SMOS_REQUIRE(x && gamma && beta && out, "add_layer_norm: null pointer");
+  const dim3 grid(grid_for(rows * kWave, kBlock, 256 * 16)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C / kWave) {
+    case 1: hipLaunchKernelGGL(add_layer_norm<1>, grid, block, 0, s, x, res, gamma, beta, out, rows, eps); break;
+    case 2: hipLaunchKernelGGL(add_layer_norm<2>, grid, block, 0, s, x, res, gamma, beta, out, rows, eps); break;
+    case 4: hipLaunchKernelGGL(add_layer_norm<4>, grid, block, 0, s, x, res, gamma, beta, out, rows, eps); break;
+    case 8: hipLaunchKernelGGL(add_layer_norm<8>, grid, block, 0, s, x, res, gamma, beta, out, rows, eps); break;
+    default:
+      set_error("add_layer_norm: C = %lld is not built (64, 128, 256, 512)", (long long)C);
+      return SMOS_ERR_UNSUPPORTED;
+  }
+  return check_launch("add_layer_norm");
+}

@@ -121,6 +121,75 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_d32(const float* __restrict__
   }
 }
 
+// The same sampler fed by the RAW query projection of DeformAttnLayer (multi_view_encoder.py:300-316): per token a row
+// qp = [M*P*2 offsets | M*P attention logits]; single level H x W, reference points = cell centres, D == 32, P <= 8.
+// Folds what the module does in five small launches -- softmax over the P logits, off / (W, H), + reference point --
+// into the sampler: lane p of a 32-lane half owns sample p.  loc = ref + off / norm and (loc * size - 0.5) keep the
+// module's operation order.
+__global__ __launch_bounds__(kBlock) void msda_fwd_qp_d32(const float* __restrict__ value, const float* __restrict__ qp,
+                                                          float* __restrict__ out, int64_t n_heads_total, int M, int H, int W,
+                                                          int P) {
+  const int lane32 = threadIdx.x & 31;
+  const int S = H * W, row = M * P * 3;
+  const int64_t wstride = (int64_t)M * 32;
+  for (int64_t hq = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5; hq < n_heads_total;
+       hq += ((int64_t)gridDim.x * blockDim.x) >> 5) {
+    const int m = (int)(hq % M);
+    const int64_t tok = hq / M;                      // b * S + q
+    const int q = (int)(tok % S);
+    const int64_t b = tok / S;
+    const float* r = qp + tok * row;
+    float logit = -INFINITY, off_x = 0.f, off_y = 0.f;
+    if (lane32 < P) {
+      off_x = r[(m * P + lane32) * 2];
+      off_y = r[(m * P + lane32) * 2 + 1];
+      logit = r[M * P * 2 + m * P + lane32];
+    }
+    // softmax over the P samples of this (token, head): lanes >= P hold -inf / 0
+    float mx = logit;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+    const float e = lane32 < P ? expf(logit - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 8);
+    const float aw = e / sum;
+    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+    int co[4] = {-1, -1, -1, -1};
+    if (lane32 < P) {
+      const float ref_x = ((float)(q % W) + 0.5f) / (float)W, ref_y = ((float)(q / W) + 0.5f) / (float)H;
+      const float loc_w = ref_x + off_x / (float)W, loc_h = ref_y + off_y / (float)H;
+      const float h_im = loc_h * H - 0.5f, w_im = loc_w * W - 0.5f;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        const bool t = h_low >= 0, bt = h_low + 1 <= H - 1, lf = w_low >= 0, rt = w_low + 1 <= W - 1;
+        co[0] = (t && lf) ? h_low * W + w_low : -1;
+        co[1] = (t && rt) ? h_low * W + w_low + 1 : -1;
+        co[2] = (bt && lf) ? (h_low + 1) * W + w_low : -1;
+        co[3] = (bt && rt) ? (h_low + 1) * W + w_low + 1 : -1;
+        cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
+      }
+    }
+    const float* vb = value + (b * S) * wstride + (int64_t)m * 32 + lane32;
+    float col = 0.f;
+    const int half_base = threadIdx.x & 32;
+    for (int p = 0; p < P; ++p) {
+      const int src = half_base + p;
+      float tap = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int o = __shfl(co[k], src);
+        const float w = __shfl(cw[k], src);
+        const float v = (o >= 0) ? vb[(int64_t)o * wstride] : 0.f;
+        tap += w * v;
+      }
+      col += tap * __shfl(aw, src);
+    }
+    out[hq * 32 + lane32] = col;
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // backward (training row f2): replaces the col2im kernel family of the reference
@@ -238,6 +307,21 @@ extern "C" int smos_msda_fwd(const void* value, const int64_t* spatial_shapes, c
                        (const double*)attn_weight, (double*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
   }
   return check_launch("msda_fwd");
+}
+
+extern "C" int smos_msda_fwd_qp(const float* value, const float* qp, float* out, int64_t N, int64_t H, int64_t W, int64_t M,
+                                int64_t D, int64_t P, smos_stream_t stream) {
+  SMOS_REQUIRE(N >= 0 && H > 0 && W > 0 && M > 0 && P > 0, "msda_fwd_qp: bad sizes");
+  if (D != 32 || P > 8) {
+    set_error("msda_fwd_qp: built for head width 32 and at most 8 points (got %lld, %lld)", (long long)D, (long long)P);
+    return SMOS_ERR_UNSUPPORTED;
+  }
+  const int64_t heads = N * H * W * M;
+  if (heads == 0) return SMOS_OK;
+  SMOS_REQUIRE(value && qp && out && H * W * M * D < (1LL << 31), "msda_fwd_qp: null pointer / map too large");
+  hipLaunchKernelGGL(msda_fwd_qp_d32, dim3(grid_for(heads * 32, kBlock, 256 * 16)), dim3(kBlock), 0, (hipStream_t)stream, value, qp, out,
+                     heads, (int)M, (int)H, (int)W, (int)P);
+  return check_launch("msda_fwd_qp");
 }
 
 extern "C" int smos_msda_bwd(const void* grad_out, const void* value, const int64_t* spatial_shapes,

@@ -265,6 +265,13 @@ class InferenceEngine:
         ops.gather_scatter(rv, sphere, scale, bev_xy, scale, out=back_cl, pts_out=point_rows)
         ops.nhwc_to_nchw(back_cl, back)
 
+    @staticmethod
+    def _add_norm(a, b, norm, c):
+        """LayerNorm(a + b) in one pass (csrc/epilogue.hip) for the token widths that kernel is built for."""
+        if c % 64 == 0 and c <= 512:
+            return ops.add_layer_norm(a.contiguous(), b.contiguous(), norm[0], norm[1], norm[2] if len(norm) > 2 else 1e-5)
+        return F.layer_norm(a + b, (c,), norm[0], norm[1], norm[2] if len(norm) > 2 else 1e-5)
+
     def _temporal_fusion(self, x2, memory, channels_last=False):
         """DeformAttnModule (multi_view_encoder.py:426-439, 245-321): the memory stream queries the current map."""
         b, c, hh, ww = x2.shape
@@ -288,13 +295,17 @@ class InferenceEngine:
             h, p = L.heads, L.points
             value = F.linear(src, *L.value).view(b, lq, h, c // h)
             qp = F.linear(query, *L.qproj)
-            off = qp[..., :h * p * 2].reshape(b, lq, h, 1, p, 2)
-            attn = F.softmax(qp[..., h * p * 2:].reshape(b, lq, h, p), -1).view(b, lq, h, 1, p)
-            loc = (self._ref + off / self._norm).contiguous()
-            sampled = ops.msda_fwd(value.contiguous(), self._shapes, self._lsi, loc, attn.contiguous())
-            query = F.layer_norm(query + F.linear(sampled, *L.out), (c,), *L.norm1)
-            ffn = F.linear(F.relu(F.linear(query, *L.lin1)), *L.lin2)
-            query = F.layer_norm(query + ffn, (c,), *L.norm2)
+            if c // h == 32 and p <= 8:
+                # softmax over the points, offset normalisation and reference points folded into the sampler
+                sampled = ops.msda_fwd_qp(value.contiguous(), qp.contiguous(), hh, ww, p)
+            else:
+                off = qp[..., :h * p * 2].reshape(b, lq, h, 1, p, 2)
+                attn = F.softmax(qp[..., h * p * 2:].reshape(b, lq, h, p), -1).view(b, lq, h, 1, p)
+                loc = (self._ref + off / self._norm).contiguous()
+                sampled = ops.msda_fwd(value.contiguous(), self._shapes, self._lsi, loc, attn.contiguous())
+            query = self._add_norm(query, F.linear(sampled, *L.out), L.norm1, c)
+            ffn = F.linear(self._linear_relu(query.view(b * lq, c), L.lin1).view(b, lq, -1), *L.lin2)
+            query = self._add_norm(query, ffn, L.norm2, c)
         if channels_last:
             return query.contiguous().view(b, hh, ww, c).permute(0, 3, 1, 2)
         return query.transpose(1, 2).reshape(b, c, hh, ww).contiguous()

@@ -420,6 +420,35 @@ def point_head(rows, wprep, m3, out=None):
     return out
 
 
+def msda_fwd_qp(value, qp, h, w, points):
+    """value [N, H*W, M, 32] contiguous, qp [N, H*W, M*P*3] contiguous (offsets | logits) -> [N, H*W, M*32]."""
+    _require_cuda("msda_fwd_qp", value, qp)
+    n, s, m, d = value.shape
+    if not (value.is_contiguous() and qp.is_contiguous()) or s != h * w or qp.shape[-1] != m * points * 3 or value.dtype != torch.float32:
+        raise RuntimeError("msda_fwd_qp: expected contiguous float32 value [N,H*W,M,D] and qp [N,H*W,M*P*3]")
+    out = torch.empty((n, s, m * d), dtype=torch.float32, device=value.device)
+    lib = _lib.load()
+    with torch.cuda.device(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, s, m, d)):
+        rc = lib.smos_msda_fwd_qp(value.data_ptr(), qp.data_ptr(), out.data_ptr(), n, h, w, m, d, points, _stream(value))
+    _lib.check(rc, "smos_msda_fwd_qp")
+    return out
+
+
+def add_layer_norm(x, res, gamma, beta, eps=1e-5):
+    """LayerNorm(x + res) over the last dimension; x / res contiguous float32 [..., C]."""
+    _require_cuda("add_layer_norm", x, res, gamma, beta)
+    if not x.is_contiguous() or (res is not None and (not res.is_contiguous() or res.shape != x.shape)):
+        raise RuntimeError("add_layer_norm: x and res must be contiguous and of equal shape")
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.smos_add_layer_norm(x.data_ptr(), res.data_ptr() if res is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                                     out.data_ptr(), x.numel() // c, c, float(eps), _stream(x))
+    _lib.check(rc, "smos_add_layer_norm")
+    return out
+
+
 def upconv_tap_weights(w, c0, c1):
     """w [Cout, Cin, 3, 3] -> [9*Cout, c1-c0]: the per-tap matrices of input channels [c0, c1), tap-major (t = 3 ky + kx)."""
     cout = w.shape[0]

@@ -311,6 +311,45 @@ def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes):
     assert (got.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("hw,m,pnt", [((64, 64), 4, 4), ((20, 36), 2, 8), ((7, 5), 4, 3)])
+def test_msda_fwd_qp_equals_module_formulation(hw, m, pnt):
+    """The sampler fed by the raw query projection (softmax, offset normalisation and reference points folded in) against
+    the module's own sequence softmax -> ref + off / (W, H) -> smos_msda_fwd.  Same arithmetic except the order of the
+    P-term softmax sum: 1e-5 of the output range."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(53)
+    h, w = hw
+    n, lq, d = 2, h * w, 32
+    value = torch.randn((n, lq, m, d), generator=gen).to(DEV)
+    qp = torch.cat((torch.randn((n, lq, m * pnt * 2), generator=gen) * 3.0, torch.randn((n, lq, m * pnt), generator=gen)), -1).to(DEV)
+    got = ops.msda_fwd_qp(value, qp, h, w, pnt)
+    shapes = torch.tensor([[h, w]], dtype=torch.long, device=DEV)
+    lsi = torch.zeros((1,), dtype=torch.long, device=DEV)
+    ys = (torch.arange(h, dtype=torch.float32, device=DEV) + 0.5) / h
+    xs = (torch.arange(w, dtype=torch.float32, device=DEV) + 0.5) / w
+    ref = torch.stack((xs[None, :].expand(h, w), ys[:, None].expand(h, w)), -1).reshape(1, lq, 1, 1, 1, 2)
+    norm = torch.tensor([w, h], dtype=torch.float32, device=DEV)
+    off = qp[..., :m * pnt * 2].reshape(n, lq, m, 1, pnt, 2)
+    attn = F.softmax(qp[..., m * pnt * 2:].reshape(n, lq, m, pnt), -1).view(n, lq, m, 1, pnt)
+    want = ops.msda_fwd(value, shapes, lsi, (ref + off / norm).contiguous(), attn.contiguous())
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("c", [64, 128, 512])
+def test_add_layer_norm_against_torch(c):
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(47)
+    x = (torch.randn((3, 1000, c), generator=gen) * 3 + 1).to(DEV)
+    r = torch.randn((3, 1000, c), generator=gen).to(DEV)
+    g, b = torch.randn(c, generator=gen).to(DEV), torch.randn(c, generator=gen).to(DEV)
+    want = F.layer_norm((x + r).double(), (c,), g.double(), b.double(), 1e-5)
+    got = ops.add_layer_norm(x, r, g, b, 1e-5)
+    assert (got.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    got1 = ops.add_layer_norm(x, None, g, b, 1e-5)
+    want1 = F.layer_norm(x.double(), (c,), g.double(), b.double(), 1e-5)
+    assert (got1.double() - want1).abs().max().item() <= 1e-5 * want1.abs().max().item()
+
+
 def test_pointnet_scatter_run_boundaries_at_cell_zero():
     """Regression: cell 0 is a legal cell.  Run ends are found with a lane shuffle; evaluated under a partial exec
     mask a lane reading a masked-off neighbour gets 0, which made a point of cell 0 at position 30 of a 32-point tile
