@@ -419,9 +419,9 @@ class InferenceEngine:
         x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
         self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])
         self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:])
-        # res2 (the third BEV stage) is independent of the past too, but it runs in decode(): that balances the two
-        # pipeline stages (encode ~4.0 ms, decode ~4.0 ms of kernel time) so both HIP streams stay busy
-        # (re-measured after the sparse first stage shortened the encoder: res2 on the encode side 158.6 vs 167.5 scans/s)
+        # res2 (the third BEV stage) is independent of the past too, but it runs in decode(): that keeps the two pipeline
+        # stages balanced so both HIP streams stay busy (re-measured after the sparse first stage shortened the encoder:
+        # res2 on the encode side 158.6 vs 167.5 scans/s)
         return {"x0cat": x0cat, "x1cat": x1cat, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
 
     def _decode_cl(self, enc, x2):
