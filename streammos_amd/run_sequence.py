@@ -36,7 +36,11 @@ def load_model(checkpoint=None, device="cuda:0", seg=False):
     return model.to(device).eval()
 
 
-def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_point_num=160000, limit=None, seq_num=3):
+def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_point_num=160000, limit=None, seq_num=3,
+                 device_preprocess=False):
+    """device_preprocess=True: only the raw scans are uploaded (each once) and the validation preprocessing runs on
+    the GPU (identical to the host path except the last ulp of asinf / atan2f) -- the host then only
+    reads files and writes labels."""
     spec = preprocess.VoxelSpec()
     files = sorted(f for f in os.listdir(os.path.join(seq_dir, "velodyne")) if f.endswith(".bin"))
     if limit:
@@ -64,10 +68,22 @@ def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_poin
             if has_gt:
                 m_ref.add(gt(fid), np.where(lab == 251, 2, np.where(lab == 9, 1, 0)))
 
+    dev_cache = {}
+
+    def dev_scan(i):
+        if i not in dev_cache:
+            dev_cache[i] = torch.from_numpy(np.ascontiguousarray(scan(i))).to(device, non_blocking=True)
+            for k in [k for k in dev_cache if k < i - 12]:
+                del dev_cache[k]
+        return dev_cache[i]
+
     for i in range(len(files)):
         idx = [min(j, len(files) - 1) for j in preprocess.window_indices(i, len(files), seq_num)]
-        sample = preprocess.build_sample([scan(j) for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
-        out = runner.step(runner.upload(sample, scan(i)), poses[i])
+        if device_preprocess:
+            out = runner.step_raw([dev_scan(j) for j in idx], [poses[j] for j in idx], frame_point_num)
+        else:
+            sample = preprocess.build_sample([scan(j) for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
+            out = runner.step(runner.upload(sample, scan(i)), poses[i])
         raw = out["raw_labels"].cpu().numpy()
         kitti.write_prediction(os.path.join(out_dir, "predictions", files[i][:-4] + ".label"), labels_012=raw)
         if "bf_raw_labels" in out:          # val_StreamMOS_seg.py:141: raw 0/1/2 words, no LUT
@@ -98,6 +114,8 @@ def main():
                     help="voxel_instance_voting.py instead of voxel_voting.py for the refined labels (needs --seg: the "
                          "clusters come from the `_bf` prediction)")
     ap.add_argument("--limit", type=int, default=None)
+    ap.add_argument("--device-preprocess", action="store_true",
+                    help="range filter / pose alignment / TTA / quantisation on the GPU: only raw scans cross PCIe")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = args.device or "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +127,7 @@ def main():
     vote = False if args.no_vote else ("instance" if args.instance_vote else True)
     for d in mine:
         out = os.path.join(args.out_dir, os.path.basename(os.path.normpath(d))) if len(args.seq_dir) > 1 else args.out_dir
-        print(json.dumps(run_sequence(model, d, out, device, vote=vote, limit=args.limit)), flush=True)
+        print(json.dumps(run_sequence(model, d, out, device, vote=vote, limit=args.limit, device_preprocess=args.device_preprocess)), flush=True)
 
 
 if __name__ == "__main__":

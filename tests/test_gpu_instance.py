@@ -153,3 +153,9 @@ def test_run_sequence_with_instance_voting(tmp_path):
         assert words.shape[0] == npts and set(np.unique(words)) <= {0, 9, 251}
         bf = np.fromfile(out / "predictions_bf" / ("%06d.label" % k), dtype=np.uint32)
         assert bf.shape[0] == npts and set(np.unique(bf)) <= {0, 1, 2}
+    # the same run with the validation preprocessing on the device (only raw scans uploaded): same files
+    out2 = tmp_path / "out_dev"
+    run_sequence.run_sequence(model, str(seq), str(out2), DEV, vote="instance", frame_point_num=2048, device_preprocess=True)
+    same = [np.mean(np.fromfile(out / "refined" / ("%06d.label" % k), dtype=np.uint32) ==
+                    np.fromfile(out2 / "refined" / ("%06d.label" % k), dtype=np.uint32)) for k in range(n)]
+    assert min(same) >= 0.99          # asinf / atan2f may differ in the last ulp between numpy and the device
