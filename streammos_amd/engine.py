@@ -431,10 +431,17 @@ class InferenceEngine:
             y = ops.upconv3x3(F.conv2d(x0cat, self.conv_1a, None, 1, 1), self.conv_1[1],
                               [(x1cat, self.conv_1z[0]), (x2, self.conv_1z[1])], LEAKY)
             size = tuple(x0cat.shape[2:])
-            aux = [F.conv2d(x0cat, *self.aux_split[0])]
-            for src, (w, b) in ((x1cat, self.aux_split[1]), (x2, self.aux_split[2])):
+
+            def head1x1(src, wb):
+                # 3 output channels: as a conv MIOpen falls back to its naive kernel; on channels-last rows it is a GEMM
+                bb, cc, hh, ww = src.shape
+                rows = src.permute(0, 2, 3, 1).reshape(bb * hh * ww, cc)
+                return torch.addmm(wb[1], rows, wb[0].reshape(wb[0].shape[0], -1).t()).view(bb, hh, ww, -1).permute(0, 3, 1, 2)
+
+            aux = [head1x1(x0cat, self.aux_split[0])]
+            for src, wb in ((x1cat, self.aux_split[1]), (x2, self.aux_split[2])):
                 # a 1x1 convolution commutes with the (linear, weights summing to 1) bilinear resize
-                aux.append(F.interpolate(F.conv2d(src, w, b), size=size, mode="bilinear", align_corners=True))
+                aux.append(F.interpolate(head1x1(src, wb), size=size, mode="bilinear", align_corners=True))
         else:
             dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
             y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
