@@ -147,6 +147,15 @@ class InferenceEngine:
             self.conv_1 = (_cl_w(self.conv_1[0]), self.conv_1[1])
             self.conv_2 = (_cl_w(self.conv_2[0]), self.conv_2[1])
             self.aux = (_cl_w(self.aux[0]), self.aux[1], self.aux[2])
+        # own fused 3x3 conv (csrc/conv3x3.hip) for the BasicBlocks with 32 / 64 channels.  Alone on the GPU it matches
+        # MIOpen's kernel and saves the separate epilogue pass (tools/ubench_conv3x3.py: 0.065 vs 0.083 ms at 32 ch x 256^2);
+        # inside the two-stream step the difference vanishes (209.3 vs 208.7 scans/s, A/B x 2) -- its LDS-resident weights
+        # leave less room for the other stream's kernels -- so MIOpen stays the default; SMOS_OWN_CONV=1 switches it on.
+        self.own_conv = os.environ.get("SMOS_OWN_CONV", "0") == "1"
+        for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
+            for p in blocks:
+                if p.kind == "basic" and p.w1.shape[0] in (32, 64) and tuple(p.w1.shape) == tuple(p.w2.shape) == (p.w1.shape[0],) * 2 + (3, 3):
+                    p.w1p, p.w2p = ops.conv3x3_prepare(p.w1), ops.conv3x3_prepare(p.w2)
         self._shapes = None
         self._lsi = None
         self._hw = None
@@ -347,6 +356,13 @@ class InferenceEngine:
             return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
+    def _own_conv_for(self, x, p):
+        """Shapes where csrc/conv3x3.hip wins (tools/ubench_conv3x3.py): C = 32 everywhere, C = 64 from 128 x 128 up."""
+        if not self.own_conv or getattr(p, "w1p", None) is None:
+            return False
+        b, c, h, w = x.shape
+        return w % 32 == 0 and (c == 32 or (c == 64 and h * w >= 128 * 128))
+
     def _block_cl(self, x, p, out=None):
         if p.kind == "down":
             a = F.conv2d(x, p.wa, None, p.stride, 1)
@@ -359,8 +375,15 @@ class InferenceEngine:
             ops.bias_act_cl(F.conv2d(x, p.wb, None, 1, p.pb), p.bb, RELU, out=both[:, c:])
             y = F.conv2d(both, p.wc, None, 1, 1)
             return ops.bias_act_cl(y, p.bc, RELU, out=out if out is not None else y, residual=x)
-        y = F.conv2d(x, p.w1, None, 1, 1)
-        ops.bias_act_cl(y, p.b1, RELU, out=y)
+        if self._own_conv_for(x, p):
+            # the library's own 3x3 conv with the epilogue fused (csrc/conv3x3.hip): as fast as MIOpen's kernel for these
+            # shapes, minus the separate bias / ReLU / residual pass
+            y = ops.conv3x3_cl(x, p.w1p, p.b1, RELU)
+            if not p.att:
+                return ops.conv3x3_cl(y, p.w2p, p.b2, RELU, residual=x, out=out)
+        else:
+            y = F.conv2d(x, p.w1, None, 1, 1)
+            ops.bias_act_cl(y, p.b1, RELU, out=y)
         y2 = F.conv2d(y, p.w2, None, 1, 1)
         dst = out if out is not None else y2
         if p.att:
