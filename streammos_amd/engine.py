@@ -147,11 +147,14 @@ class InferenceEngine:
             self.conv_1 = (_cl_w(self.conv_1[0]), self.conv_1[1])
             self.conv_2 = (_cl_w(self.conv_2[0]), self.conv_2[1])
             self.aux = (_cl_w(self.aux[0]), self.aux[1], self.aux[2])
-        # own fused 3x3 conv (csrc/conv3x3.hip) for the BasicBlocks with 32 / 64 channels.  Alone on the GPU it matches
-        # MIOpen's kernel and saves the separate epilogue pass (tools/ubench_conv3x3.py: 0.065 vs 0.083 ms at 32 ch x 256^2);
-        # inside the two-stream step the difference vanishes (209.3 vs 208.7 scans/s, A/B x 2) -- its LDS-resident weights
-        # leave less room for the other stream's kernels -- so MIOpen stays the default; SMOS_OWN_CONV=1 switches it on.
-        self.own_conv = os.environ.get("SMOS_OWN_CONV", "0") == "1"
+        # own fused 3x3 conv (csrc/conv3x3.hip) for BasicBlocks.  Alone on the GPU it matches MIOpen's kernel and saves the
+        # separate epilogue pass (tools/ubench_conv3x3.py: 0.065 vs 0.083 ms at 32 ch x 256^2, 0.052 vs 0.062 at 64 ch x
+        # 128^2).  Inside the two-stream step the 32-channel blocks gain (216.5 / 217.2 vs 213.6 / 213.8 scans/s, same box),
+        # the 64-channel ones lose (210.6): their 144 KB of LDS-resident weights allow one block per CU and crowd out the
+        # other stream's kernels.  Default: 32 channels only (SMOS_OWN_CONV=0 disables, SMOS_OWN_CONV=32,64 widens).
+        sel = os.environ.get("SMOS_OWN_CONV", "32")
+        self.own_conv_channels = tuple(int(v) for v in sel.split(",") if v.strip() in ("32", "64"))
+        self.own_conv = len(self.own_conv_channels) > 0
         for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
             for p in blocks:
                 if p.kind == "basic" and p.w1.shape[0] in (32, 64) and tuple(p.w1.shape) == tuple(p.w2.shape) == (p.w1.shape[0],) * 2 + (3, 3):
@@ -357,11 +360,11 @@ class InferenceEngine:
 
     # ---- channels-last path -----------------------------------------------------------------------
     def _own_conv_for(self, x, p):
-        """Shapes where csrc/conv3x3.hip wins (tools/ubench_conv3x3.py): C = 32 everywhere, C = 64 from 128 x 128 up."""
+        """BasicBlocks that run on csrc/conv3x3.hip (see the note in __init__)."""
         if not self.own_conv or getattr(p, "w1p", None) is None:
             return False
         b, c, h, w = x.shape
-        return w % 32 == 0 and (c == 32 or (c == 64 and h * w >= 128 * 128))
+        return w % 32 == 0 and c in self.own_conv_channels
 
     def _block_cl(self, x, p, out=None):
         if p.kind == "down":
