@@ -30,8 +30,10 @@ ALG_GB_PER_SCAN = 11.2           # 2.806 GB/sample x 4 TTA
 FRAME_POINT_NUM = 160000         # config/StreamMOS.py:44 (Val.frame_point_num)
 
 
-def algorithmic_bytes(label):
-    """Bytes a kernel launch must move if every operand is touched exactly once (float32)."""
+def algorithmic_bytes(label, ctx=None):
+    """Bytes a kernel launch must move if every operand is touched exactly once (float32).  ctx: per-run facts that
+    the label does not carry (``stem_rows``: mean number of occupied input cells = compact rows per launch)."""
+    ctx = ctx or {}
     name, dims = label.split("[", 1)
     dims = dims.rstrip("]")
     if name == "voxel_maxpool_fwd":
@@ -41,15 +43,16 @@ def algorithmic_bytes(label):
         d = len(dst.split("x"))
         return 4 * (bs * c * n + bs * n * d + bs * c * cells)
     if name == "pointnet_scatter":
-        # fused point_pre + input scatter (zero fill of the target included in the timed span): reads the 7-channel
-        # point features and the 2 used coordinate columns, produces the [B,512,512,T*64] grid and the t=0
-        # point features; the 491 MB intermediate of the unfused form is not counted because it is never moved.
-        # (With the sparse first stage the grid is produced as compact rows of its occupied cells: the figure below
-        # stays the reference op's output size, `traffic` shows what actually moves.)
+        # fused point_pre + input scatter: reads the 7-channel point features and the 2 used coordinate columns, writes
+        # the t = 0 point features [B, N, 64] and the scatter target.  The engine launches the COMPACT form (one
+        # T*64-float row per occupied cell): stem_rows x 768 B; the dense 805 MB grid of the
+        # reference is never built and is not charged.  The dense form (SMOS_SPARSE_STEM=0) is charged the grid.
         src, dst = dims.split("->")
         b, t, n = (int(v) for v in src.split("x"))
         cells = int(np.prod([int(v) for v in dst.split("x")]))
-        return 4 * (b * t * 7 * n + b * t * n * 2 + b * cells * t * 64 + b * n * 64)
+        rows = ctx.get("stem_rows")
+        target = rows * t * 64 if rows is not None else b * cells * t * 64
+        return int(4 * (b * t * 7 * n + b * t * n * 2 + target + b * n * 64))
     if name in ("gather_scatter", "gather_scatter_cl"):
         src, n, dst = dims.split("->")
         b, c, h, w = (int(v) for v in src.split("x"))
@@ -66,26 +69,101 @@ def algorithmic_bytes(label):
     if name == "point_head":
         b, n = (int(v) for v in dims.split("x"))
         return 4 * b * n * (192 + 3)
+    if name == "conv_cl":
+        # own implicit-GEMM conv (csrc/conv_igemm.hip): label B x Cin x H x W -> Cout x Ho x Wo k KHxKW [+res]
+        geo = _conv_geometry(dims)
+        res = geo["b"] * geo["cout"] * geo["ho"] * geo["wo"] if geo["res"] else 0
+        return 4 * (geo["b"] * geo["cin"] * geo["h"] * geo["w"] + geo["b"] * geo["cout"] * geo["ho"] * geo["wo"] + res +
+                    geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"])
     if name in ("stem_gemm", "stem_epilogue", "stem_mark+compact"):
-        # sparse DownSample2D 192 -> 32, stride 2: the dense op it replaces reads the grid once and writes the half-
-        # resolution map; the three spans of the sparse form share that figure (gemm: grid in; epilogue: map out)
+        # sparse DownSample2D 192 -> 32, stride 2 on the occupied cells: rows in (gemm), half-resolution map out (epilogue)
         b, h, w, cin = (int(v) for v in dims.split("x"))
+        rows = ctx.get("stem_rows", b * h * w)
         if name == "stem_gemm":
-            return 4 * b * h * w * cin
+            return int(4 * rows * cin)
         if name == "stem_epilogue":
             return 4 * b * (h // 2) * (w // 2) * 32
         return 4 * b * h * w
     return 0
 
 
-def algorithmic_flops(label):
-    """FLOPs of a launch whose time is set by the matrix cores rather than by HBM (0 = not such a kernel)."""
+def _conv_geometry(dims):
+    src, rest = dims.split("->")
+    dst, rest = rest.split("k", 1)
+    b, cin, h, w = (int(v) for v in src.split("x"))
+    cout, ho, wo = (int(v) for v in dst.split("x"))
+    res = rest.endswith("+res")
+    kh, kw = (int(v) for v in rest.replace("+res", "").split("x"))
+    return {"b": b, "cin": cin, "h": h, "w": w, "cout": cout, "ho": ho, "wo": wo, "kh": kh, "kw": kw, "res": res}
+
+
+def algorithmic_flops(label, ctx=None):
+    """FLOPs of a launch that runs on the matrix cores (0 = not such a kernel)."""
     name, dims = label.split("[", 1)
     dims = dims.rstrip("]")
     if name == "point_head":
         b, n = (int(v) for v in dims.split("x"))
         return 2 * b * n * (192 * 96 + 96 * 64 + 64 * 3)
+    if name == "pointnet_scatter":
+        # 7 -> 64 (the bias rides on an 8th input feature = 1) -> 64 per point, on v_mfma_f32_32x32x2_f32
+        src, _ = dims.split("->")
+        b, t, n = (int(v) for v in src.split("x"))
+        return 2 * b * t * n * (8 * 64 + 64 * 64)
+    if name == "conv_cl":
+        geo = _conv_geometry(dims)
+        return 2 * geo["b"] * geo["ho"] * geo["wo"] * geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"]
     return 0
+
+
+def executed_flops(engine, b, n, t, stem_class_rows):
+    """FLOPs the engine really executes for one scan (batch of b TTA samples, n padded points, t stacked scans):
+    walks the engine's own folded weights.  Differs from the reference's dense count (0.53 TFLOP) by the
+    sparse first stage (only occupied cells, only the taps their parity class feeds) and by conv_1 running as a direct
+    conv on the fine map + tap GEMMs of the coarse maps at their own resolution."""
+    hb, wb = engine.bev_hw
+    total = 2.0 * b * t * n * (8 * 64 + 64 * 64)                                # point MLP
+    total += sum(2.0 * r * 192 * 32 * (taps + 1) for r, taps in zip(stem_class_rows, (1, 2, 2, 4)))   # sparse stem
+
+    def conv(w, px):
+        return 2.0 * b * px * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+
+    def stage(blocks, h, w, first_sparse=False):
+        nonlocal total
+        for i, p in enumerate(blocks):
+            if p.kind == "down":
+                if not (first_sparse and i == 0):
+                    total += conv(p.wa, (h // p.stride) * (w // p.stride)) + conv(p.wp, h * w)
+                h, w = h // p.stride, w // p.stride
+            elif p.kind == "unbalance":
+                total += conv(p.wa, h * w) + conv(p.wb, h * w) + conv(p.wc, h * w)
+            else:
+                total += conv(p.w1, h * w) + conv(p.w2, h * w)
+        return h, w
+
+    sparse = engine.sparse_stem and engine.stem_w is not None
+    if not sparse:
+        total -= sum(2.0 * r * 192 * 32 * (taps + 1) for r, taps in zip(stem_class_rows, (1, 2, 2, 4)))
+    h0, w0 = stage(engine.header_bev, hb, wb, first_sparse=sparse)
+    stage(engine.header_rv, 32, 1024)
+    h1, w1 = stage(engine.res1_bev, h0, w0)
+    stage(engine.res1_rv, 16, 512)
+    h2, w2 = stage(engine.res2, h1, w1)
+    c = engine.query_embed.shape[1]
+    for L in engine.layers:                                                      # temporal fusion: five linears per layer
+        lin = c * c + c * L.qproj[0].shape[0] + c * c + 2 * c * L.lin1[0].shape[0]
+        total += 2.0 * b * h2 * w2 * lin
+    c0, cc1, cc2 = engine.conv_1a.shape[1], engine.conv_1z[0].shape[1], engine.conv_1z[1].shape[1]
+    co = engine.conv_1a.shape[0]
+    if engine.upconv:
+        total += 2.0 * b * (h0 * w0 * 9 * c0 * co + h1 * w1 * 9 * cc1 * co + h2 * w2 * 9 * cc2 * co)
+    else:
+        total += 2.0 * b * h0 * w0 * 9 * (c0 + cc1 + cc2) * co
+    total += conv(engine.conv_2[0], h0 * w0)
+    k = engine.aux[2]
+    total += 2.0 * b * k * (h0 * w0 * c0 + h1 * w1 * cc1 + h2 * w2 * cc2)
+    heads = 2 if engine.refine is not None else 1
+    total += heads * 2.0 * b * n * (192 * 96 + 96 * 64 + 64 * k)
+    return total
 
 
 def pmc_traffic(label):
@@ -245,27 +323,41 @@ def main():
 
     if rank == 0:
         value = world * args.steps / elapsed
+        eng = getattr(model, "_engine", None)
+        ctx, stem_class_rows = {}, (0, 0, 0, 0)
+        if eng is not None and eng.sparse_stem and eng.stem_w is not None:
+            # occupancy of the frames the timed region cycled through (device-side counts of the stem plan, read here,
+            # outside the timed region): rows per launch of the compact scatter target / the sparse first stage
+            from streammos_amd import ops as _ops
+            metas = [_ops.stem_plan(d["pcds_coord"], *eng.bev_hw).meta.cpu().numpy() for d, _ in dev_frames]
+            stem_class_rows = tuple(float(np.mean([m[c] for m in metas])) for c in range(4))
+            ctx["stem_rows"] = float(np.mean([m[11] for m in metas]))
         roof = None
         if dominant and dominant in timed:
             calls, total_ms, mean_ms = timed[dominant]
-            ab = algorithmic_bytes(dominant)
-            af = algorithmic_flops(dominant)
-            if af and af / (FP32_PEAK_TFLOPS * 1e12) > ab / (HBM_PEAK_GBS * 1e9):
-                # the matrix-core time of the launch exceeds its HBM time: an MFMA-bound kernel (the fused point head)
+            ab = algorithmic_bytes(dominant, ctx)
+            af = algorithmic_flops(dominant, ctx)
+            t_hbm, t_mfma = ab / (HBM_PEAK_GBS * 1e9), af / (FP32_PEAK_TFLOPS * 1e12)
+            common = {"kernel": dominant, "traffic": pmc_traffic(dominant), "algorithmic_bytes_per_launch": ab,
+                      "algorithmic_flops_per_launch": af, "hbm_floor_ms": round(1e3 * t_hbm, 4),
+                      "mfma_floor_ms": round(1e3 * t_mfma, 4), "avg_launch_ms": round(mean_ms, 4), "launches": calls,
+                      "clock": "HIP events (torch.cuda.Event) recorded around the launch on the stream handed to the C ABI, "
+                               "inside the timed region; profiles/r02*_kernel_stats.csv holds rocprofv3's mean for the same kernel"}
+            if t_mfma > t_hbm:
+                # the matrix-core time of the launch exceeds its HBM time: an MFMA-bound kernel
                 achieved = af / (mean_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dominant),
-                        "algorithmic_flops_per_launch": af, "algorithmic_bytes_per_launch": ab,
-                        "avg_launch_ms": round(mean_ms, 4), "launches": calls}
+                roof = dict({"bound": "mfma", "achieved": round(achieved, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / FP32_PEAK_TFLOPS, 4)}, **common)
             else:
                 achieved = ab / (mean_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
-                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(mean_ms, 4), "launches": calls}
-        if roof and dominant.startswith("point_head") and getattr(model, "_engine", None) is not None:
+                roof = dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4)}, **common)
+            if ctx.get("stem_rows") is not None:
+                roof["stem_rows_per_launch"] = round(ctx["stem_rows"])
+        if roof and dominant.startswith("point_head") and eng is not None:
             # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
             from streammos_amd import ops as _ops
-            eng, d0 = model._engine, dev_frames[0][0]
+            d0 = dev_frames[0][0]
             bs, n = d0["pcds_xyzi"].shape[0], d0["pcds_xyzi"].shape[3]
             rows = torch.randn((bs, n, 192), dtype=torch.float32, device=device)
             torch.cuda.synchronize()
@@ -275,10 +367,9 @@ def main():
             iso = kt_iso.summary()[dominant][2]
             roof["isolated_launch_ms"] = round(iso, 4)
             roof["isolated_frac"] = round(roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-        if roof and dominant.startswith("pointnet_scatter") and getattr(model, "_engine", None) is not None:
-            # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
+        if roof and dominant.startswith("pointnet_scatter") and eng is not None:
             from streammos_amd import ops as _ops
-            eng, d0 = model._engine, dev_frames[0][0]
+            d0 = dev_frames[0][0]
             bs, t, _, n = d0["pcds_xyzi"].shape[:4]
             rows = torch.empty((bs, n, 192), dtype=torch.float32, device=device)
             compact = eng.sparse_stem and eng.stem_w is not None        # the form the engine launches (engine._encode_cl)
@@ -297,7 +388,15 @@ def main():
                                               bev, pts_out=rows[:, :, :64], zero_fill=True)
             iso = kt_iso.summary()[dominant][2]
             roof["isolated_launch_ms"] = round(iso, 4)
-            roof["isolated_frac"] = round(roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if roof["bound"] == "mfma":
+                roof["isolated_frac"] = round(roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+            else:
+                roof["isolated_frac"] = round(roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        exec_tflop = None
+        if eng is not None and eng.layout == "cl":
+            d0 = dev_frames[0][0]
+            bs, t, _, n = d0["pcds_xyzi"].shape[:4]
+            exec_tflop = executed_flops(eng, bs, n, t, stem_class_rows) / 1e12
         line = {
             "metric": "LiDAR scans/sec (StreamMOS streaming inference + voxel voting)",
             "value": round(value, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,12 +410,16 @@ def main():
             "path_roofline": {"bound": "hbm", "achieved": round(value / world * ALG_GB_PER_SCAN, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(value / world * ALG_GB_PER_SCAN / HBM_PEAK_GBS, 4),
                               "note": "scans/s/GPU x 11.2 GB algorithmic bytes per scan (SURVEY.md 8d)"},
-            "path_compute_roofline": {"bound": "mfma", "achieved": round(value / world * ALG_TFLOP_PER_SCAN, 1),
-                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(value / world * ALG_TFLOP_PER_SCAN / FP32_PEAK_TFLOPS, 4),
-                                      "note": "dense-equivalent rate: the reference's 0.53 TFLOP/scan (fp32) x scans/s against the fp32 "
-                                              "MFMA/vector peak; the engine executes ~0.37 TFLOP of them (sparse first stage, "
-                                              "conv_1 as tap GEMMs at source resolution), so this is not a hard ceiling"},
+            "path_compute_roofline": (None if exec_tflop is None else
+                                      {"bound": "mfma", "achieved": round(value / world * exec_tflop, 1),
+                                       "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(value / world * exec_tflop / FP32_PEAK_TFLOPS, 4),
+                                       "executed_tflop_per_scan": round(exec_tflop, 4),
+                                       "dense_equivalent_tflops": round(value / world * ALG_TFLOP_PER_SCAN, 1),
+                                       "note": "scans/s/GPU x the FLOPs the engine really executes per scan (bench.executed_flops "
+                                               "walks the engine's layers and the frames' occupancy) against the fp32 MFMA = "
+                                               "vector peak; dense_equivalent = the reference's 0.53 TFLOP/scan x scans/s, kept for "
+                                               "comparison only (the sparse first stage and the restructured conv_1 skip work)"}),
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }

@@ -109,18 +109,9 @@ using namespace smos;
 template <int C, int kThreads>
 static int launch_conv3x3(const Conv3Args& a, int per_cu, hipStream_t s, const char* what) {
   const size_t lds = (size_t)9 * (C / 32) * (C / 2) * 64 * sizeof(float);
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_cl<C, kThreads>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      set_error("%s: device setup failed", what);
-      return SMOS_ERR_LAUNCH;
-    }
-    cus = prop.multiProcessorCount;
-  }
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv3x3_cl<C, kThreads>), lds, 0, &ks, what)) return rc;
+  const int cus = ks.cus;
   const int64_t tiles = (int64_t)a.B * a.H * (a.W / 32);
   const int64_t want = (tiles + kThreads / 64 - 1) / (kThreads / 64);
   const int64_t cap = (int64_t)cus * per_cu;

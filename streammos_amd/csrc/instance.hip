@@ -147,9 +147,9 @@ __global__ __launch_bounds__(kBlock) void box_vote(const float* __restrict__ pts
     float x = row[0], y = row[1], z = row[2];
     if (!pose.identity) {
       const double dx = x, dy = y, dz = z;
-      x = (float)(((pose.m[0] * dx + pose.m[1] * dy) + pose.m[2] * dz) + pose.m[3]);
-      y = (float)(((pose.m[4] * dx + pose.m[5] * dy) + pose.m[6] * dz) + pose.m[7]);
-      z = (float)(((pose.m[8] * dx + pose.m[9] * dy) + pose.m[10] * dz) + pose.m[11]);
+      x = (float)pose_row_f64(pose.m + 0, dx, dy, dz);
+      y = (float)pose_row_f64(pose.m + 4, dx, dy, dz);
+      z = (float)pose_row_f64(pose.m + 8, dx, dy, dz);
     }
     if (!((x > clo0) && (x < chi0) && (y > clo1) && (y < chi1) && (z > clo2) && (z < chi2))) continue;
     for (int k = 0; k < K; ++k) {

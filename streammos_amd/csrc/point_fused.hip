@@ -397,17 +397,9 @@ static int pointnet_scatter_launch(const float* xyzi, const float* coord, int32_
   a.S = (int)(B * T); a.T = (int)T; a.N = (int)N; a.K = K; a.H = (int)H; a.W = (int)W;
   a.tiles_per_sample = (int)((N + kNt - 1) / kNt);
   // persistent waves: exactly as many blocks as are resident at once
-  static int resident = 0;
-  if (resident == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pointnet_scatter, kBlock, 0) != hipSuccess || per_cu < 1) {
-      set_error("pointnet_scatter: occupancy query failed");
-      return SMOS_ERR_LAUNCH;
-    }
-    resident = per_cu * prop.multiProcessorCount;
-  }
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&pointnet_scatter), 0, kBlock, &ks, "pointnet_scatter")) return rc;
+  const int64_t resident = (int64_t)ks.per_cu * ks.cus;
   const int64_t n_nt = (int64_t)a.S * ((N + kNt - 1) / kNt);
   SMOS_REQUIRE(n_nt < (1LL << 30), "pointnet_scatter: too many points for 32-bit tile indices");
   const int64_t want = (n_nt + 3) / 4;

@@ -134,18 +134,9 @@ extern "C" int smos_point_head(const float* rows, int64_t row_pitch, const float
   SMOS_REQUIRE(K1 == kK1 && M1 == kM1 && M2 == kM2 && M3 >= 1 && M3 <= 32, "point_head: built for 192 -> 96 -> 64 -> (<=32)");
   SMOS_REQUIRE(B > 0 && N > 0 && row_pitch >= K1 && row_pitch % 4 == 0 && B * ((N + 31) / 32) < (1LL << 31), "point_head: bad sizes");
   SMOS_REQUIRE(rows && wprep && out && (reinterpret_cast<uintptr_t>(rows) & 15) == 0, "point_head: null / unaligned pointer");
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&point_head), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(kHeadLds * sizeof(float))) != hipSuccess) {
-      set_error("point_head: device setup failed");
-      return SMOS_ERR_LAUNCH;
-    }
-    cus = prop.multiProcessorCount;
-  }
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&point_head), kHeadLds * sizeof(float), 0, &ks, "point_head")) return rc;
+  const int cus = ks.cus;
   HeadArgs a;
   a.rows = rows; a.wprep = wprep; a.out = out; a.rp = row_pitch; a.B = (int)B; a.N = (int)N; a.M3 = (int)M3;
   const int64_t tiles = B * ((N + 31) / 32);

@@ -33,9 +33,9 @@ __global__ __launch_bounds__(kBlock) void prep_transform_mask(const float* __res
     float x = p.x, y = p.y, z = p.z;
     if (!pose.identity) {
       const double dx = x, dy = y, dz = z;
-      x = (float)(((pose.m[0] * dx + pose.m[1] * dy) + pose.m[2] * dz) + pose.m[3]);
-      y = (float)(((pose.m[4] * dx + pose.m[5] * dy) + pose.m[6] * dz) + pose.m[7]);
-      z = (float)(((pose.m[8] * dx + pose.m[9] * dy) + pose.m[10] * dz) + pose.m[11]);
+      x = (float)pose_row_f64(pose.m + 0, dx, dy, dz);
+      y = (float)pose_row_f64(pose.m + 4, dx, dy, dz);
+      z = (float)pose_row_f64(pose.m + 8, dx, dy, dz);
     }
     reinterpret_cast<float4*>(moved)[i] = make_float4(x, y, z, p.w);
     mask[i] = (x >= g.lo[0] && x < g.hi[0] && y >= g.lo[1] && y < g.hi[1] && z >= g.lo[2] && z < g.hi[2]) ? 1 : 0;

@@ -38,6 +38,23 @@ inline int check_launch(const char* what) {
     }                                    \
   } while (0)
 
+// Launch facts of one kernel on ONE device: CU count, the dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize
+// is a per-device attribute) and, if asked for, the resident blocks per CU.  Looked up per (kernel, current device) under
+// a mutex, so a process that drives several GPUs -- or several threads -- gets each device set up exactly once.
+struct KernelSetup {
+  int cus = 0;
+  int per_cu = 0;   // hipOccupancyMaxActiveBlocksPerMultiprocessor (0 when not requested)
+};
+int kernel_setup(const void* fn, size_t dyn_lds_bytes, int occupancy_block, KernelSetup* out, const char* what);
+
+// One row of the 4x4 pose difference times (x, y, z, 1) in float64, in the operation order of the dgemm micro-kernel
+// numpy's ``mat.dot`` runs for datasets/utils.py:116-126 (one accumulator per output element, k = 0..3, fused
+// multiply-adds): written with the round-to-nearest intrinsics so that -ffp-contract has nothing to decide.  The result
+// is rounded to float32 once by the caller, as the reference's ``pcds_out[..., :3] = pcds_tmp[..., :3]`` does.
+__device__ __forceinline__ double pose_row_f64(const double* m, double x, double y, double z) {
+  return __dadd_rn(__fma_rn(m[2], z, __fma_rn(m[1], y, __dmul_rn(m[0], x))), m[3]);
+}
+
 struct Dims4 {
   int64_t v[4];
 };

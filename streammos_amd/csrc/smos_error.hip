@@ -1,6 +1,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "smos_common.h"
 
 namespace smos {
@@ -10,6 +14,41 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int kernel_setup(const void* fn, size_t dyn_lds_bytes, int occupancy_block, KernelSetup* out, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, KernelSetup> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("%s: hipGetDevice failed", what);
+    return SMOS_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = table.find({fn, dev});
+  if (it == table.end()) {
+    KernelSetup ks;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+      set_error("%s: device query failed", what);
+      return SMOS_ERR_LAUNCH;
+    }
+    ks.cus = cus;
+    if (dyn_lds_bytes > 0 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds_bytes) != hipSuccess) {
+      set_error("%s: cannot opt in to %zu bytes of dynamic LDS", what, dyn_lds_bytes);
+      return SMOS_ERR_LAUNCH;
+    }
+    if (occupancy_block > 0 &&
+        (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ks.per_cu, fn, occupancy_block, dyn_lds_bytes) != hipSuccess ||
+         ks.per_cu < 1)) {
+      set_error("%s: occupancy query failed", what);
+      return SMOS_ERR_LAUNCH;
+    }
+    it = table.emplace(std::make_pair(fn, dev), ks).first;
+  }
+  *out = it->second;
+  return SMOS_OK;
 }
 }  // namespace smos
 

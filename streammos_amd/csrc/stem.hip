@@ -265,18 +265,9 @@ extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const i
   SMOS_REQUIRE(bev && meta && wprep4 && y4, "stem_gemm: null pointer");
   for (int c = 0; c < 4; ++c) SMOS_REQUIRE(wprep4[c] && y4[c], "stem_gemm: null class pointer");
   const size_t lds = (size_t)5 * kStemSteps * 64 * sizeof(float);   // the largest class: 4 taps + the pool branch
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-      set_error("stem_gemm: device setup failed");
-      return SMOS_ERR_LAUNCH;
-    }
-    cus = prop.multiProcessorCount;
-  }
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&stem_gemm), lds, 0, &ks, "stem_gemm")) return rc;
+  const int cus = ks.cus;
   StemGemmArgs a;
   a.bev = bev; a.row_cell = row_cell; a.meta = meta;
   for (int c = 0; c < 4; ++c) {

@@ -58,9 +58,9 @@ __device__ __forceinline__ void load_xyz(const float* __restrict__ row, const Po
     // float32 -> float64 matmul with w = 1 -> float32, as datasets/utils.py:116-126; the sum order is the
     // dot-product order of a row of the 4x4 with (x, y, z, 1)
     const double dx = x, dy = y, dz = z;
-    x = (float)(((p.m[0] * dx + p.m[1] * dy) + p.m[2] * dz) + p.m[3]);
-    y = (float)(((p.m[4] * dx + p.m[5] * dy) + p.m[6] * dz) + p.m[7]);
-    z = (float)(((p.m[8] * dx + p.m[9] * dy) + p.m[10] * dz) + p.m[11]);
+    x = (float)pose_row_f64(p.m + 0, dx, dy, dz);
+    y = (float)pose_row_f64(p.m + 4, dx, dy, dz);
+    z = (float)pose_row_f64(p.m + 8, dx, dy, dz);
   }
 }
 

@@ -163,6 +163,7 @@ class InferenceEngine:
         self._lsi = None
         self._hw = None
         self.miopen_search = True
+        self.ws_tag = 0
 
     # ---- parameter extraction -----------------------------------------------------------
     def _block(self, m):
@@ -248,11 +249,16 @@ class InferenceEngine:
         return (pred,) + a3 + (x2,)
 
     def _block_ws(self, p, n_floats):
-        """Scratch of one channel-attention block.  Every block owns its buffer: blocks of different pipeline stages run
-        concurrently on different HIP streams, a shared scratch would be a data race."""
-        ws = getattr(p, "ws", None)
+        """Scratch of one channel-attention block (plane sums written by one kernel, read by the next).  Keyed by
+        (block, HIP stream, ws_tag): blocks of different pipeline stages run concurrently on different streams, the same
+        block may run on two streams at once (encode(t) on the main stream next to encode(t+1) on the side stream), and
+        hipGraphs captured from one engine for several TTA groups replay concurrently with the addresses baked in
+        (``ws_tag`` = group index, set by StreamRunner._capture) -- a shared scratch would be a data race in each case."""
+        table = p.__dict__.setdefault("ws", {})
+        key = (torch.cuda.current_stream(self.device).cuda_stream, self.ws_tag)
+        ws = table.get(key)
         if ws is None or ws.numel() < n_floats:
-            ws = p.ws = torch.zeros(n_floats, dtype=torch.float32, device=self.device)
+            ws = table[key] = torch.zeros(n_floats, dtype=torch.float32, device=self.device)
         return ws
 
     def _run_stage(self, x, blocks, out=None):

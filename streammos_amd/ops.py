@@ -530,14 +530,25 @@ _stem_ws = {}
 
 
 def _stream_workspace(tag, shape, dtype, device):
-    """Worst-case-sized scratch of the sparse first stage (0.8 + 0.4 GB at the validation shape), one per (HIP stream,
-    tag, shape): consecutive frames on a stream reuse it in stream order instead of holding a fresh allocation per frame
-    that the host has enqueued ahead of the GPU."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, tuple(shape), dtype)
+    """Scratch of the sparse first stage, one flat buffer per (device, HIP stream, tag), grown to the largest request
+    seen: consecutive frames on a stream reuse it in stream order instead of holding a fresh allocation per frame that
+    the host has enqueued ahead of the GPU.  The returned view is valid until the next request with the same tag on the
+    same stream (callers consume it within the frame).  ``release_stream_workspaces`` frees them."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, dtype)
+    need = 1
+    for d in shape:
+        need *= int(d)
     buf = _stem_ws.get(key)
-    if buf is None:
-        buf = _stem_ws[key] = torch.empty(shape, dtype=dtype, device=device)
-    return buf
+    if buf is None or buf.numel() < need:
+        buf = _stem_ws[key] = torch.empty(need, dtype=dtype, device=device)
+    return buf[:need].view(shape)
+
+
+def release_stream_workspaces(device=None, stream=None):
+    """Drops the per-stream scratch (all of it, or one device's / one HIP stream's); StreamRunner.close() calls this."""
+    for key in list(_stem_ws):
+        if (device is None or key[0] == str(device)) and (stream is None or key[1] == stream):
+            del _stem_ws[key]
 
 
 class StemPlan:
@@ -576,23 +587,27 @@ def stem_plan(coord, h, w):
 
 
 def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
-    """pointnet_scatter into the COMPACT row table of `plan`: returns rows [B*H*W (capacity), T*64]; only the first
-    plan.meta[11] rows exist (zero-filled here, on the device-side count) -- the dense grid is never materialised."""
+    """pointnet_scatter into the COMPACT row table of `plan`: returns rows [min(B*H*W, B*T*N) (capacity), T*64], a view
+    of this stream's scratch (valid until the next call on the stream); only the first plan.meta[11] rows exist (zero-filled here, on the device-side count) -- the dense grid is never materialised."""
     _require_cuda("pointnet_scatter_rows", xyzi, coord, w1, b1, w2, b2, pts_out)
     b, t, cin, n = xyzi.shape[:4]
     k = coord.shape[3]
     if not (xyzi.is_contiguous() and coord.is_contiguous()):
         raise RuntimeError("pointnet_scatter_rows: xyzi and coord must be contiguous")
     cout = w2.shape[0]
-    rows = _stream_workspace("stem_rows", (plan.b * plan.h * plan.w, t * cout), torch.float32, xyzi.device)
+    # capacity: an occupied cell holds at least one point, so min(cells, points) rows always suffice
+    rows = _stream_workspace("stem_rows", (min(plan.b * plan.h * plan.w, b * t * n), t * cout), torch.float32, xyzi.device)
     po_b = po_n = 0
     if pts_out is not None:
         po_b, po_n = _rows("pointnet_scatter_rows", pts_out, cout)
     lib = _lib.load()
     st = _stream(xyzi)
-    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
-        _lib.check(lib.smos_stem_zero_rows(rows.data_ptr(), plan.meta.data_ptr(), t * cout, st), "smos_stem_zero_rows")
-        rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+    with torch.cuda.device(xyzi.device):
+        with profiling.span("stem_zero_rows[%dx%dx%dx%d]" % (b, plan.h, plan.w, t * cout)):
+            _lib.check(lib.smos_stem_zero_rows(rows.data_ptr(), plan.meta.data_ptr(), t * cout, st), "smos_stem_zero_rows")
+        # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
+        with profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
+            rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                             b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
                                             pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
                                             plan.h, plan.w, cin, w1.shape[0], cout, st)
@@ -608,8 +623,10 @@ def sparse_downsample(src, plan, wprep, bias, compact, out=None):
     b, h, w = plan.b, plan.h, plan.w
     cin = src.shape[-1]
     dev = src.device
-    if src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != b * h * w * cin:
+    if src.dtype != torch.float32 or not src.is_contiguous() or (not compact and src.numel() != b * h * w * cin):
         raise RuntimeError("sparse_downsample: src must be contiguous float32 with B*H*W rows of Cin")
+    if compact and src.dim() != 2:
+        raise RuntimeError("sparse_downsample: the compact row table is [rows, Cin]")
     cout = bias.shape[0]
     per = b * (h // 2) * (w // 2)
     ys = [_stream_workspace("stem_y%d" % k, (per, (taps + 1) * cout), torch.float32, dev)                # worst-case capacity

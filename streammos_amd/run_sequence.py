@@ -85,6 +85,8 @@ def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_poin
             sample = preprocess.build_sample([scan(j) for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
             out = runner.step(runner.upload(sample, scan(i)), poses[i])
         raw = out["raw_labels"].cpu().numpy()
+        if device_preprocess:
+            runner.check_last_raw_sample()      # a scan that leaves no padding is an error, as on the host path
         kitti.write_prediction(os.path.join(out_dir, "predictions", files[i][:-4] + ".label"), labels_012=raw)
         if "bf_raw_labels" in out:          # val_StreamMOS_seg.py:141: raw 0/1/2 words, no LUT
             kitti.write_prediction(os.path.join(out_dir, "predictions_bf", files[i][:-4] + ".label"),

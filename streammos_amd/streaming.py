@@ -209,9 +209,15 @@ class StreamRunner:
         # capture-safe engine configuration: under MIOpen's solver search the channels-last convs resolve to
         # composable-kernel grouped-conv solvers whose argument staging does not survive graph replay (observed: 2 %
         # wrong logits); the NCHW engine with MIOpen's default (immediate-mode) solvers replays bit-exactly.
+        saved = (self.model.engine_layout, self.model.engine_miopen_search)
         self.model.engine_layout = "nchw"
         self.model.engine_miopen_search = False
         self.model.invalidate_engine()
+        with torch.no_grad():
+            eng = self.model._engine_for(dev["pcds_xyzi"])
+        if eng is None:
+            raise RuntimeError("StreamRunner(graph=True) needs the fused GPU engine (eval mode, fast_inference)")
+        self._g_engine = eng            # the captured kernels read this engine's folded weights: keep it alive
         v = dev["pcds_xyzi"].shape[0]
         k = self.split if v % self.split == 0 else 1
         per = v // k
@@ -219,6 +225,7 @@ class StreamRunner:
         side = torch.cuda.Stream(self.device)
         for gi in range(k):
             sl = slice(gi * per, (gi + 1) * per)
+            eng.ws_tag = gi             # per-group scratch: the groups' graphs replay concurrently (engine._block_ws)
             g_in = {key: dev[key][sl].clone() for key in self._KEYS}
             batch = {key: g_in[key].unsqueeze(0) for key in self._KEYS}
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -242,6 +249,9 @@ class StreamRunner:
                 graphs[first] = (g, pred)
             self._groups.append({"in": g_in, "mem": g_mem, "graphs": graphs, "slice": sl,
                                  "stream": torch.cuda.Stream(self.device)})
+        eng.ws_tag = 0
+        # the caller's model goes back to its own configuration; its next eager call rebuilds its engine
+        self.model.engine_layout, self.model.engine_miopen_search = saved
         self._g_shape = tuple(dev["pcds_xyzi"].shape)
         self._g_pred = torch.empty((v,) + tuple(self._groups[0]["graphs"][True][1].shape[1:]), dtype=torch.float32,
                                    device=self.device)
@@ -270,6 +280,14 @@ class StreamRunner:
         if self.voter is not None:
             self.voter.reset()
 
+    def close(self):
+        """Frees the per-stream scratch this runner's HIP streams hold (ops._stream_workspace: ~1.2 GB per stream at the
+        validation shape).  The runner stays usable; the scratch is re-allocated on the next frame."""
+        main = torch.cuda.current_stream(self.device).cuda_stream
+        ops.release_stream_workspaces(self.device, main)
+        if self._side is not None:
+            ops.release_stream_workspaces(self.device, self._side.cuda_stream)
+
     def upload(self, sample, raw_scan=None):
         """Host sample (streammos_amd.preprocess.build_sample) -> device-resident inputs."""
         dev = {k: torch.from_numpy(np.ascontiguousarray(sample[k])).to(self.device)
@@ -279,6 +297,8 @@ class StreamRunner:
         dev["n_valid"] = int(sample["valid_mask"].sum())
         if raw_scan is not None:
             dev["raw_scan"] = torch.from_numpy(np.ascontiguousarray(raw_scan)).to(self.device)
+        dev["ready"] = torch.cuda.Event()            # consumers on other HIP streams wait for the copies above
+        dev["ready"].record(torch.cuda.current_stream(self.device))
         return dev
 
     @torch.no_grad()
@@ -296,7 +316,15 @@ class StreamRunner:
         # (the reference does exactly that, datasets/data_StreamMOS.py:424-467)
         built = self._pre.build(dev_scans, [inv_cur.dot(np.asarray(p, dtype=np.float64)) for p in poses])
         built["raw_scan"] = dev_scans[0]
+        self._last_built = built        # run_sequence checks its in_range_counts when it reads the labels back
         return self.step(built, poses[0])
+
+    def check_last_raw_sample(self):
+        """The device preprocessing drops points beyond frame_point_num instead of raising (no sync on the hot path);
+        call this where the labels are read back anyway to get the host path's error (preprocess.pad_scan)."""
+        built = getattr(self, "_last_built", None)
+        if built is not None and getattr(self, "_pre", None) is not None:
+            self._pre.check_capacity(built)
 
     def _pipelined(self, dev, next_dev):
         """Two HIP streams: encode(t+1) on the side stream while frame t is decoded on the main one.  (Putting the serial
@@ -313,6 +341,15 @@ class StreamRunner:
             enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
         self._pre_enc = None
         if next_dev is not None:                        # encoder of the NEXT frame, concurrent with this decode
+            # the side stream must start behind the producers of next_dev.  Inputs made by upload() carry the event
+            # recorded behind their H2D copies; anything else (e.g. device preprocessing on main) is ordered behind
+            # main's whole tail.  Two encodes of one engine may run concurrently (frame 0: encode(t) on main beside
+            # encode(t+1) here): every piece of engine scratch is keyed by stream (engine._block_ws, ops._stream_workspace).
+            ready = next_dev.get("ready")
+            if ready is not None:
+                self._side.wait_event(ready)
+            else:
+                self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 nxt = eng.encode(next_dev["pcds_xyzi"], next_dev["pcds_coord"], next_dev["pcds_sphere_coord"])
             for t in list(nxt.values()) + [next_dev[k] for k in self._KEYS]:

@@ -32,16 +32,21 @@ def test_infer_matches_reference_golden(golden, model):
             pred, a0, a1, a2, memory = model.infer(tb, i, memory)
             ref = g["e2e_f%d_pred" % i]
             got = pred.cpu().numpy()
-            # fp32 everywhere; MIOpen vs MKL-DNN summation order over ~40 layers: 1e-3 of the logit range,
-            # which keeps >= 99.5 % of the argmax labels (north_star budget: +-0.1 moving IoU)
-            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
-            assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.995
-            np.testing.assert_allclose(memory[:, ::8, ::4, ::4].cpu().numpy(), g["e2e_f%d_mem_sub" % i], rtol=0, atol=2e-3)
-            stats = g["e2e_f%d_mem_stats" % i]
-            assert abs(memory.double().abs().sum().item() - stats[1]) <= 1e-4 * stats[1]
+            # fp32 on both sides; what differs is the summation order of ~40 conv layers (own MFMA convs / MIOpen vs
+            # MKL-DNN) and the float64 BatchNorm folding.  Observed on MI355X: ~1.5e-6 of the logit range, all labels
+            # equal; the bars are ~10x that, so a wrong tap or channel in any fused kernel fails.
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            agree = (got.argmax(1) == ref.argmax(1)).mean()
+            mem_ref = g["e2e_f%d_mem_sub" % i]
+            mem_err = np.abs(memory[:, ::8, ::4, ::4].cpu().numpy() - mem_ref).max() / np.abs(mem_ref).max()
             aux = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].cpu().numpy()
             ref_aux = g["e2e_f%d_aux_sub" % i]
-            assert np.abs(aux - ref_aux).max() <= 1e-3 * np.abs(ref_aux).max()
+            aux_err = np.abs(aux - ref_aux).max() / np.abs(ref_aux).max()
+            print("golden frame %d: logits %.2e of range, labels %.6f, memory %.2e, aux %.2e" % (i, err, agree, mem_err, aux_err))
+            assert err <= 2e-5 and agree >= 0.9999, (i, err, agree)
+            assert mem_err <= 5e-5 and aux_err <= 2e-5, (i, mem_err, aux_err)
+            stats = g["e2e_f%d_mem_stats" % i]
+            assert abs(memory.double().abs().sum().item() - stats[1]) <= 1e-5 * stats[1]
 
 
 def test_stream_runner_with_voting_matches_oracle(model):
@@ -230,8 +235,8 @@ def test_epilogue_kernels_against_torch(name):
 
 def test_full_size_scan_against_cpu_oracle(model):
     """BASELINE.json configs[1] shape (B=4 TTA, T=3, N=160000, 120k-point synthetic scans): two chained frames on
-    the GPU engine vs the CPU oracle.  Tolerance: fp32 both sides, different conv algorithms (MIOpen Winograd /
-    implicit GEMM vs MKL-DNN direct) and BN folding: 1e-3 of the logit range, >= 99.8 % identical labels."""
+    the GPU engine vs the CPU oracle.  fp32 both sides, different summation order (MFMA implicit GEMM vs MKL-DNN direct)
+    and BN folding: 2e-5 of the logit range, >= 99.99 % identical labels."""
     import bench
     frames = bench.make_frames(2, seq_seed=7)
     oracle = net_torch.OracleNet({k: v.cpu() for k, v in model.state_dict().items()})
@@ -244,18 +249,19 @@ def test_full_size_scan_against_cpu_oracle(model):
             want, w0, w1, w2, mem_cpu = oracle.stage_forward(*(torch.from_numpy(sample[k]) for k in
                                                               ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), mem_cpu)
             got = pred.cpu()
-            scale = want.abs().max().item()
-            assert (got - want).abs().max().item() <= 1e-3 * scale, i
+            err = (got - want).abs().max().item() / want.abs().max().item()
             n_valid = int(sample["valid_mask"].sum())
-            lab_g = got.argmax(1)[:, :n_valid]
-            lab_c = want.argmax(1)[:, :n_valid]
-            assert (lab_g == lab_c).float().mean().item() >= 0.998, i
+            agree = (got.argmax(1)[:, :n_valid] == want.argmax(1)[:, :n_valid]).float().mean().item()
             tta_g = (torch.softmax(got, 1).mean(0).argmax(0)[:n_valid, 0])
             tta_c = net_torch.tta_labels(want)[0][:n_valid]
-            assert (tta_g == tta_c).float().mean().item() >= 0.998, i
-            assert (mem_gpu.cpu() - mem_cpu).abs().max().item() <= 2e-3 * mem_cpu.abs().max().item()
-            for g_, c_ in ((a0, w0), (a1, w1), (a2, w2)):
-                assert (g_.cpu() - c_).abs().max().item() <= 1e-3 * c_.abs().max().item()
+            tta_agree = (tta_g == tta_c).float().mean().item()
+            mem_err = (mem_gpu.cpu() - mem_cpu).abs().max().item() / mem_cpu.abs().max().item()
+            aux_err = max((g_.cpu() - c_).abs().max().item() / c_.abs().max().item() for g_, c_ in ((a0, w0), (a1, w1), (a2, w2)))
+            print("full-size frame %d: logits %.2e of range, labels %.6f, TTA labels %.6f, memory %.2e, aux %.2e"
+                  % (i, err, agree, tta_agree, mem_err, aux_err))
+            # ~10x the error observed on MI355X (summation order only: fp32 on both sides)
+            assert err <= 2e-5 and agree >= 0.9999 and tta_agree >= 0.9999, (i, err, agree, tta_agree)
+            assert mem_err <= 5e-5 and aux_err <= 2e-5, (i, mem_err, aux_err)
 
 
 def test_run_sequence_writes_reference_file_formats(tmp_path):
@@ -397,3 +403,81 @@ def test_seg_variant_engine_matches_reference_golden(golden):
     sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
     out = runner.step(runner.upload(sample, scans[0]), poses[0])
     assert out["bf_raw_labels"].shape == out["raw_labels"].shape and int(out["bf_raw_labels"].max()) <= 2
+
+
+def test_eight_concurrent_streams_full_size(model):
+    """BASELINE.json configs[2]: 8 sequences advanced in lock step as ONE batch of 32 samples at the validation shape
+    (N = 160 000), every stream's memory and voting window resident.  Stream 0 is checked against the CPU oracle, every
+    stream against its own solo run (logits, raw labels, voted labels), two chained frames."""
+    import bench
+    S, n_frames = 8, 2
+    per_stream = [bench.make_frames(n_frames, seq_seed=200 + q) for q in range(S)]
+    up = streaming.StreamRunner(model, DEV, vote=False)
+    solo = []
+    for q in range(S):
+        r = streaming.StreamRunner(model, DEV, vote=True)
+        r.voter.window = n_frames
+        outs = []
+        for f in range(n_frames):
+            sample, raw, pose = per_stream[q][f]
+            o = r.step(r.upload(sample, raw), pose)
+            outs.append((o["pred_cls"].clone(), o["raw_labels"].clone(), [(k, l.clone()) for k, l in o["voted"]]))
+        solo.append(outs)
+        del r
+    ms = streaming.MultiStreamRunner(model, DEV, n_streams=S, vote=True)
+    for v in ms.voters:
+        v.window = n_frames
+    oracle = net_torch.OracleNet({k: v.cpu() for k, v in model.state_dict().items()})
+    torch.set_num_threads(bench.host_cores())
+    mem_cpu = None
+    worst = [0.0, 1.0]
+    for f in range(n_frames):
+        devs = [up.upload(per_stream[q][f][0], per_stream[q][f][1]) for q in range(S)]
+        pred, outs = ms.step(ms.batch_inputs(devs), [per_stream[q][f][2] for q in range(S)])
+        assert pred.shape[0] == 4 * S
+        for q in range(S):
+            want_pred, want_raw, want_voted = solo[q][f]
+            err = (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() / want_pred.abs().max().item()
+            same = (outs[q]["raw_labels"] == want_raw).float().mean().item()
+            worst = [max(worst[0], err), min(worst[1], same)]
+            assert err <= 1e-5 and same >= 0.9999, (f, q, err, same)
+            assert [k for k, _ in outs[q]["voted"]] == [k for k, _ in want_voted]
+            for (_, a), (_, b) in zip(outs[q]["voted"], want_voted):
+                assert (a == b).float().mean().item() >= 0.9999
+        s0 = per_stream[0][f][0]
+        with torch.no_grad():
+            want, _, _, _, mem_cpu = oracle.stage_forward(*(torch.from_numpy(s0[k]) for k in
+                                                            ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), mem_cpu)
+        got = pred[:4].cpu()
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        n_valid = int(s0["valid_mask"].sum())
+        agree = (got.argmax(1)[:, :n_valid] == want.argmax(1)[:, :n_valid]).float().mean().item()
+        print("8 streams, frame %d: stream 0 vs oracle %.2e of range, labels %.6f; batched vs solo worst %.2e / %.6f"
+              % (f, err, agree, worst[0], worst[1]))
+        assert err <= 2e-5 and agree >= 0.9999, (f, err, agree)
+    print("8 streams: peak HBM allocated %.1f GB" % (torch.cuda.max_memory_allocated() / 1e9))
+
+
+def test_pipelined_runner_on_a_warm_engine_at_full_size(model):
+    """Two sequences back to back through ONE pipelined runner at the validation shape (reset() in between, engine and
+    scratch warm): on frame 0 of the second sequence encode(t) has just been issued on the main stream when encode(t+1)
+    starts on the side stream -- both through the same engine.  Must equal the serial runner frame for frame."""
+    import bench
+    seqs = [bench.make_frames(3, seq_seed=300 + q) for q in range(2)]
+    res = {}
+    for pipe in (False, True):
+        runner = streaming.StreamRunner(model, DEV, vote=False, pipeline=pipe)
+        outs = []
+        for frames in seqs:
+            runner.reset()
+            devs = [runner.upload(s, raw) for s, raw, _ in frames]
+            for i in range(len(frames)):
+                o = runner.step(devs[i], frames[i][2], next_dev=devs[i + 1] if i + 1 < len(frames) else None)
+                outs.append((o["pred_cls"].clone(), o["raw_labels"].clone()))
+        torch.cuda.synchronize()
+        res[pipe] = outs
+        runner.close()
+    for k, ((p0, r0), (p1, r1)) in enumerate(zip(res[False], res[True])):
+        # same kernels on the same inputs; a library conv that splits K with atomic adds may differ in the last bits
+        assert torch.equal(p0, p1) or (p0 - p1).abs().max().item() <= 1e-6 * p0.abs().max().item(), k
+        assert (r0 == r1).float().mean().item() >= 0.99999, k

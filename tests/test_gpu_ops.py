@@ -535,3 +535,24 @@ def test_gather_scatter_channels_last_against_unfused_ops(c, hw_g, hw_o, sg, ss)
     rows2 = torch.zeros((b, n, c), device=DEV)
     ops.gather_scatter_cl(grid, gcoord, sg, pts_out=rows2)
     assert torch.equal(rows2, rows[:, :, 8:])
+
+
+def test_msda_module_forward_matches_reference_golden(golden):
+    """MSDeformAttn.forward (deformattn/modules/ms_deform_attn.py:78-116) as a module: value / offset / weight
+    projections, softmax over the points, offset normalisation, the HIP sampler, output projection -- against the
+    reference module's output on the same seeded weights (tests/golden/make_golden.py::gen_msda)."""
+    from streammos_amd import synth
+    from streammos_amd.refapi.deformattn.modules import MSDeformAttn
+    g = golden("ops_msda")
+    q, ref, src, shapes, lsi = cases.msda_module_case()
+    check_inputs(g, "msda_module_in_sha", q, ref, src)
+    mod = MSDeformAttn(d_model=128, n_levels=1, n_heads=4, n_points=4).eval()
+    sd = synth.seeded_state_dict({("cross_attn." + k): v for k, v in mod.state_dict().items()})
+    mod.load_state_dict({k[len("cross_attn."):]: v for k, v in sd.items()})
+    mod = mod.to(DEV)
+    with torch.no_grad():
+        y = mod(_t(q), _t(ref), _t(src), _t(shapes), _t(lsi))
+    want = g["msda_module_out"]
+    err = np.abs(y.cpu().numpy() - want).max() / np.abs(want).max()
+    print("MSDeformAttn.forward vs reference: %.2e of the output range" % err)
+    assert y.shape == want.shape and err <= 1e-5
