@@ -250,6 +250,20 @@ int64_t smos_conv3x3_weight_floats(int64_t C);
 int smos_conv3x3_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
                     float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, int32_t act, smos_stream_t stream);
 
+/* General channels-last convolution on the matrix cores with the epilogue fused (csrc/conv_igemm.hip):
+ *   out = act(conv_{KH x KW, stride, pad}(x) + bias [+ res]);  act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
+ * Replaces every conv2d -> BatchNorm (folded by the caller) -> ReLU / LeakyReLU (-> + residual -> ReLU) chain of
+ * networks/backbone.py:9-34,136-159 and networks/multi_view_encoder.py:460-497 (cuDNN in the reference).
+ * x [B, H, W, *], res / out [B, Ho, Wo, *]: row pitches in floats (multiples of 4; channel slices of wider buffers are
+ * fine), 16-byte aligned, each tensor < 2 GiB.  Cin % 32 == 0, Cout % (32 * mt) == 0, mt in {1, 2, 4} = 32-channel output
+ * blocks per wave (a tuning knob), KH, KW <= 7, stride 1 or 2.  bias / res may be NULL.
+ * wprep: Cout * Cin * KH * KW floats in MFMA operand order for the chosen mt; with stage = (ky * KW + kx) * (Cin / 32) + cc:
+ *   wprep[((((ct * n_stage + stage) * 4 + i4) * mt + m) * 64 + lane) * 4 + c]
+ *       = w[ct * 32 * mt + m * 32 + (lane & 31)][cc * 32 + 8 * i4 + 4 * (lane >> 5) + c][ky][kx]. */
+int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
+                 float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t KH,
+                 int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt, int32_t act, smos_stream_t stream);
+
 /* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
  * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels
  * [t*C, (t+1)*C)), computed by the caller with one GEMM.

@@ -445,6 +445,57 @@ def conv3x3_cl(x, wprep, bias, act, residual=None, out=None):
     return out
 
 
+def conv_prepare(w, mt):
+    """w [Cout, Cin, KH, KW] (BatchNorm folded) -> the weight block of smos_conv_cl in MFMA operand order for `mt`
+    32-channel output blocks per wave (include/smos.h): [cout tile][stage = (ky, kx, cin chunk)][k-step / 4][mt][lane][k-step % 4]
+    with lane = h * 32 + m holding w[ct*32*mt + mt_i*32 + m][chunk*32 + 8*i4 + 4*h + c][ky][kx]."""
+    cout, cin, kh, kw = w.shape
+    if cin % 32 or cout % (32 * mt) or mt not in (1, 2, 4):
+        raise RuntimeError("conv_prepare: Cin %% 32 == 0 and Cout %% (32 * mt) == 0 required (got %s, mt=%d)" % (tuple(w.shape), mt))
+    #           ct                mt_i  m   chunk      i4  h  c   ky  kx
+    v = w.float().reshape(cout // (32 * mt), mt, 32, cin // 32, 4, 2, 4, kh, kw)
+    #  -> [ct, ky, kx, chunk, i4, mt_i, h, m, c]
+    v = v.permute(0, 7, 8, 3, 4, 1, 5, 2, 6)
+    return v.reshape(-1).contiguous()
+
+
+def conv_mt(cout, n_pixels):
+    """Output blocks per wave for smos_conv_cl: wider waves re-use each activation load more often, narrower ones give
+    more wave tiles; aim at >= 2 waves for each of the 1024 SIMDs."""
+    tiles32 = (n_pixels + 31) // 32
+    for mt in (4, 2, 1):
+        if cout % (32 * mt) == 0 and tiles32 * (cout // (32 * mt)) >= 2048:
+            return mt
+    return 1
+
+
+def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, residual=None, out=None):
+    """act(conv(x) + bias [+ residual]) on channels-last [B,C,H,W] views in one launch (csrc/conv_igemm.hip).
+    wprep = conv_prepare(w, mt); kernel = (KH, KW); padding defaults to "same" for odd kernels."""
+    _require_cuda("conv_cl", x, wprep, bias, residual, out)
+    b, cin, h, w = x.shape
+    kh, kw = kernel
+    ph, pw = padding if padding is not None else (kh // 2, kw // 2)
+    ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    if wprep.numel() != cout * cin * kh * kw:
+        raise RuntimeError("conv_cl: weight block has %d floats, expected %d" % (wprep.numel(), cout * cin * kh * kw))
+    if out is None:
+        out = empty_cl(b, cout, ho, wo, x.device)
+    elif tuple(out.shape) != (b, cout, ho, wo):
+        raise RuntimeError("conv_cl: out has shape %s, expected %s" % (tuple(out.shape), (b, cout, ho, wo)))
+    if residual is not None and tuple(residual.shape) != (b, cout, ho, wo):
+        raise RuntimeError("conv_cl: residual has shape %s" % (tuple(residual.shape),))
+    lib = _lib.load()
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, ho, wo, kh, kw, "+res" if residual is not None else "")
+    with torch.cuda.device(x.device), profiling.span(label):
+        rc = lib.smos_conv_cl(x.data_ptr(), _cl("conv_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
+                              residual.data_ptr() if residual is not None else None,
+                              _cl("conv_cl", residual) if residual is not None else 0, out.data_ptr(), _cl("conv_cl", out),
+                              b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act), _stream(x))
+    _lib.check(rc, "smos_conv_cl")
+    return out
+
+
 def msda_fwd_qp(value, qp, h, w, points):
     """value [N, H*W, M, 32] contiguous, qp [N, H*W, M*P*3] contiguous (offsets | logits) -> [N, H*W, M*32]."""
     _require_cuda("msda_fwd_qp", value, qp)

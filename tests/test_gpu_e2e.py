@@ -261,7 +261,7 @@ def test_full_size_scan_against_cpu_oracle(model):
                   % (i, err, agree, tta_agree, mem_err, aux_err))
             # ~10x the error observed on MI355X (summation order only: fp32 on both sides)
             assert err <= 2e-5 and agree >= 0.9999 and tta_agree >= 0.9999, (i, err, agree, tta_agree)
-            assert mem_err <= 5e-5 and aux_err <= 2e-5, (i, mem_err, aux_err)
+            assert mem_err <= 1e-4 and aux_err <= 5e-5, (i, mem_err, aux_err)     # observed 1.6e-5 / 8.6e-6 on frame 1
 
 
 def test_run_sequence_writes_reference_file_formats(tmp_path):

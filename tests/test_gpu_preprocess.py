@@ -25,15 +25,15 @@ def test_device_preprocess_matches_host(beams, azimuth, npad):
     assert int(built["prefix"][-1]) == n_valid == npad - host["pad_length"]
     xyzi, coord, sph = (built[k].cpu().numpy() for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"))
     assert xyzi.shape == host["pcds_xyzi"].shape and coord.shape == host["pcds_coord"].shape
-    # the float64 pose product is summed in a fixed order here and in BLAS order on the host: the float32
-    # results are equal except for 1-ulp differences on a handful of points
-    d = np.abs(coord - host["pcds_coord"])
-    assert (d == 0).mean() > 0.9999 and d.max() <= 2e-4
-    d = np.abs(xyzi - host["pcds_xyzi"])
-    report = [(c, float((d[:, :, c] == 0).mean()), float(d[:, :, c].max())) for c in range(7)]
-    assert (d == 0).mean() > 0.9999 and d.max() <= 1e-3, report
-    # asinf / atan2f vs numpy's SIMD routines: a few ulp on the angle, i.e. <= 1e-3 of a range-image cell,
-    # and the same range-image cell (after the model's 0.5 scale) for all but a vanishing fraction of points
+    # pose alignment (float64 product in dgemm order, rounded to float32 once), range mask, compaction, padding, TTA
+    # flips, BEV quantisation and the 7-channel point feature are bit-exact against the host restatement, which is
+    # bit-exact against the reference (tests/test_oracle_golden.py::test_preprocess_matches_reference)
+    assert np.array_equal(coord, host["pcds_coord"]), int((coord != host["pcds_coord"]).sum())
+    assert np.array_equal(xyzi, host["pcds_xyzi"]), int((xyzi != host["pcds_xyzi"]).sum())
+    # the range-view coordinates go through arcsin / arctan2: numpy evaluates them with its own float32 SIMD routines
+    # (whose last bit depends on the host CPU's dispatch: the reference is not bit-reproducible across hosts here), the
+    # device with asinf / atan2f.  Measured: 3-5 % of the values differ by <= 1 ulp of the angle (3e-5 / 2.4e-4 of a
+    # range-image cell); the same range-image cell (after the model's 0.5 scale) for all but a vanishing fraction
     ds = np.abs(sph - host["pcds_sphere_coord"])
     assert ds.max() <= 2e-3
     same_cell = np.floor(sph * 0.5) == np.floor(host["pcds_sphere_coord"] * 0.5)
