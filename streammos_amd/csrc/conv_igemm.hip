@@ -24,6 +24,8 @@
 //   epilogue   = out = act(acc + bias [+ residual]) from the accumulators, 16-byte stores (lane (p, h), register r <->
 //                channel 32 mt + 8 (r >> 2) + 4 h + (r & 3)); inputs, residual and output may be channel slices of
 //                wider channels-last buffers (row pitches).
+#include <stdlib.h>
+
 #include "smos_common.h"
 
 namespace smos {
@@ -50,10 +52,6 @@ struct ConvArgs {
   int r_bytes, o_bytes, cout_bytes;   // B * Ho * Wo * rp * 4, B * Ho * Wo * op * 4, Cout * 4
 };
 
-struct ConvTile {      // the 32-pixel row segment a wave works on
-  int b, y, x0, ct;
-  bool valid;
-};
 
 // Ring barrier.  __syncthreads() would also do, but its workgroup fence makes hipcc wait vmcnt(0) -- draining the operand
 // prefetch of the next two stages once per stage.  Only LDS traffic has to be ordered here: every wave drains its own LDS
@@ -65,6 +63,21 @@ __device__ __forceinline__ void ring_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Scheduling fence: a wave issues in order, and an MFMA that depends on the previous one (same accumulator) cannot issue
+// before it has finished (64 cycles) -- so everything that is NOT an MFMA only overlaps with the matrix pipe if it sits
+// BETWEEN MFMAs in program order.  The stage body below is cut into MFMA groups (G) and small bookkeeping segments (M);
+// the fences keep hipcc from collecting the segments in front of or behind the MFMA block.
+#define SMOS_FENCE()                                                                          \
+  do {                                                                                        \
+    asm volatile("" ::: "memory"); /* IR level: loads and stores stay on their side */        \
+    __builtin_amdgcn_sched_barrier(0); /* machine scheduler: nothing crosses, MFMAs included */ \
+  } while (0)
+
+struct ConvCursor {    // a position in the block's stream of stages: item (= 4 tiles) and tap / channel chunk inside it
+  int it, s, dy, dx, ch;
+  int ct, xt, yq, b;
+};
+
 template <int MT>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 3 slots x 256 * MT float4
@@ -72,88 +85,121 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
-  const int iters = (a.n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // a block owns a contiguous range of items, so that the cursors advance by carries instead of divisions
+  const int per_block = (a.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int first = (int)blockIdx.x * per_block;
+  const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
   const int total = iters * a.nstage;
   if (total <= 0) return;
 
-  auto tile_of = [&](int it) {
-    ConvTile t;
-    const int item = (int)blockIdx.x + it * (int)gridDim.x;
-    t.valid = it < iters;
-    const int q = t.valid ? item : 0;
-    t.ct = q % a.nct;
-    int u = q / a.nct;
-    const int xt = u % a.xt;
+  auto cursor_at_first = [&]() {
+    ConvCursor c;
+    c.it = c.s = c.dy = c.dx = c.ch = 0;
+    c.ct = first % a.nct;
+    int u = first / a.nct;
+    c.xt = u % a.xt;
     u /= a.xt;
-    const int yq = u % a.hq;
-    t.b = u / a.hq;
-    t.y = yq * 4 + wave;
-    t.x0 = xt * 32;
-    t.valid = t.valid && t.y < a.Ho;
-    return t;
+    c.yq = u % a.hq;
+    c.b = u / a.hq;
+    return c;
+  };
+  // one stage further: channel chunk fastest, then the tap column, the tap row, then the next item (cout tile fastest).
+  // Selects only -- the stage body stays one basic block.
+  auto advance = [&](ConvCursor& c) {
+    const bool ch_wrap = c.ch + 1 == a.nch;
+    c.ch = ch_wrap ? 0 : c.ch + 1;
+    const bool dx_wrap = ch_wrap && c.dx + 1 == a.KW;
+    c.dx = dx_wrap ? 0 : (ch_wrap ? c.dx + 1 : c.dx);
+    c.dy = dx_wrap ? c.dy + 1 : c.dy;
+    const bool tile_wrap = c.s + 1 == a.nstage;
+    c.s = tile_wrap ? 0 : c.s + 1;
+    c.dy = tile_wrap ? 0 : c.dy;
+    c.it += tile_wrap ? 1 : 0;
+    const bool ct_wrap = tile_wrap && c.ct + 1 == a.nct;
+    c.ct = ct_wrap ? 0 : (tile_wrap ? c.ct + 1 : c.ct);
+    const bool xt_wrap = ct_wrap && c.xt + 1 == a.xt;
+    c.xt = xt_wrap ? 0 : (ct_wrap ? c.xt + 1 : c.xt);
+    const bool yq_wrap = xt_wrap && c.yq + 1 == a.hq;
+    c.yq = yq_wrap ? 0 : (xt_wrap ? c.yq + 1 : c.yq);
+    c.b += yq_wrap ? 1 : 0;
   };
 
-  // activations as a raw buffer: [0, x_bytes) readable, everything else reads as zero
+  // activations / bias / residual / output as raw buffers: a missing operand is a zero-length buffer (reads as zero); a
+  // lane outside the image gets an offset past the end (loads return zero = the convolution's padding, stores are
+  // dropped).  No load sits under a lane-dependent branch -- hipcc would stop counting and wait vmcnt(0) at the next use,
+  // draining the prefetch every stage.
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-
-  // ---- prefetch cursor: the stage whose operands are being requested (two ahead of the one being computed) ----
-  int pf_it = 0, pf_s = 0, pf_dy = 0, pf_dx = 0, pf_ch = 0;
-  ConvTile pf = tile_of(0);
-  auto issue = [&](float4 (&bset)[4], float4 (&areg)[MT]) {
-    // weights first: they are the first thing this stage waits for (vmcnt retires in order).  No load sits under a
-    // lane-dependent branch -- hipcc would stop counting and wait vmcnt(0) at the next use, draining this prefetch every
-    // stage: the activations come through a buffer descriptor whose range check returns zeros for the lanes outside the
-    // image (their offset is pushed past the end), which is the convolution's zero padding for free.
-    const float4* wsrc = a.w + ((int64_t)(pf.ct * a.nstage + pf_s)) * kSlot + tid;      // past the last tile: slice of item 0
-#pragma unroll
-    for (int m = 0; m < MT; ++m) areg[m] = wsrc[256 * m];
-    const int yy = pf.y * a.S - a.PH + pf_dy;
-    const int xx = (pf.x0 + p) * a.S - a.PW + pf_dx;
-    const bool ok = pf.valid && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-    const unsigned off = (unsigned)(((pf.b * a.H + yy) * a.W + xx) * (int)a.xp + pf_ch * 32 + 4 * h) * 4u;
-    const unsigned voff = ok ? off : 0x80000000u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + 32u * j, 0, 0);
-      bset[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-    // advance: channel chunk fastest, then the tap column, the tap row, the tile
-    ++pf_s;
-    if (++pf_ch == a.nch) {
-      pf_ch = 0;
-      if (++pf_dx == a.KW) {
-        pf_dx = 0;
-        ++pf_dy;
-      }
-    }
-    if (pf_s == a.nstage) {
-      pf_s = pf_dy = pf_dx = 0;
-      ++pf_it;
-      pf = tile_of(pf_it);
-    }
-  };
-
-  // ---- compute cursor ----
-  int c_it = 0, c_s = 0;
-  ConvTile cur = tile_of(0);
-  f32x16 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-
-  // bias / residual / output as raw buffers too: a missing operand is a zero-length buffer (reads as zero), lanes past
-  // the image edge use an offset past the end (loads return zero, stores are dropped) -- no load or store of the
-  // epilogue sits under a branch, so the eight loads of a 32-channel block are in flight together.
   const __amdgpu_buffer_rsrc_t bsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
 
+  ConvCursor pfb = cursor_at_first();      // activations: stage being requested (two ahead of the one being computed)
+  ConvCursor pfa = cursor_at_first();      // weights: slice being requested (three ahead)
+  ConvCursor cur = cursor_at_first();      // stage being computed
+
+  auto load_b = [&](float4 (&bset)[4]) {
+    const int y = pfb.yq * 4 + wave;
+    const int yy = y * a.S - a.PH + pfb.dy;
+    const int xx = (pfb.xt * 32 + p) * a.S - a.PW + pfb.dx;
+    // bitwise: a short-circuit && becomes a branch and splits the stage body
+    const bool ok = (pfb.it < iters) & (y < a.Ho) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W);
+    const unsigned off = (unsigned)(((pfb.b * a.H + yy) * a.W + xx) * (int)a.xp + pfb.ch * 32 + 4 * h) * 4u;
+    const unsigned voff = ok ? off : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + 32u * j, 0, 0);
+      bset[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  // the weight slice in flight: named registers (an array here ends up in scratch memory for MT > 1)
+  float4 ar0, ar1, ar2, ar3;
+  auto load_a = [&]() {
+    const int slice = pfa.it < iters ? pfa.ct * a.nstage + pfa.s : 0;      // past the last tile: any valid slice
+    const float4* wsrc = a.w + (int64_t)slice * kSlot + tid;
+    ar0 = wsrc[0];
+    if constexpr (MT > 1) ar1 = wsrc[256];
+    if constexpr (MT > 2) {
+      ar2 = wsrc[512];
+      ar3 = wsrc[768];
+    }
+  };
+  auto park = [&](int slot) {
+    float4* dst = ring + slot * kSlot + tid;
+    dst[0] = ar0;
+    if constexpr (MT > 1) dst[256] = ar1;
+    if constexpr (MT > 2) {
+      dst[512] = ar2;
+      dst[768] = ar3;
+    }
+  };
+  auto read_a = [&](float4 (&af)[4][MT], int slot, int i4) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[i4][mt] = ring[slot * kSlot + (i4 * MT + mt) * 64 + lane];
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+  auto mfma_group = [&](const float4 (&af)[4][MT], const float4& bv, int i4) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].x, bv.x, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].y, bv.y, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].z, bv.z, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].w, bv.w, acc[mt], 0, 0, 0);
+  };
+
   auto epilogue = [&]() {
-    const bool store = cur.valid && cur.x0 + p < a.Wo;
-    const int pix = (cur.b * a.Ho + cur.y) * a.Wo + cur.x0 + p;
+    const int y = cur.yq * 4 + wave, x = cur.xt * 32 + p;
+    const bool store = (y < a.Ho) & (x < a.Wo);
+    const int pix = (cur.b * a.Ho + y) * a.Wo + x;
     const int cbase = cur.ct * 32 * MT + 4 * h;
     const unsigned boff = (unsigned)cbase * 4u;
     const unsigned roff = store ? (unsigned)(pix * (int)a.rp + cbase) * 4u : 0x80000000u;
@@ -185,67 +231,63 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     }
   };
 
-  auto compute = [&](const float4 (&bset)[4], int slot) {
-    const float4* as = ring + slot * kSlot + lane;
-#pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float4 av = as[(i4 * MT + mt) * 64];
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bset[i4].x, acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bset[i4].y, acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bset[i4].z, acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bset[i4].w, acc[mt], 0, 0, 0);
-      }
-    }
-  };
-
-  auto park = [&](const float4 (&areg)[MT], int slot) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) ring[slot * kSlot + tid + 256 * m] = areg[m];
-  };
-
-  auto finish_stage = [&]() {
-    if (++c_s == a.nstage) {
-      epilogue();
-      c_s = 0;
-      ++c_it;
-      cur = tile_of(c_it);
-    }
-  };
-
-  float4 b0[4], b1[4], b2[4], ar[MT];
-  // prologue: stages 0 and 1 requested, their weight slices in ring slots 0 and 1
-  issue(b0, ar);
-  park(ar, 0);
-  issue(b1, ar);
-  park(ar, 1);
+  float4 b0[4], b1[4], b2[4], af[4][MT];
+  // ---- prologue: slices 0 and 1 in the ring, slice 2 in registers, activations of stages 0 and 1 requested ----
+  load_a();
+  advance(pfa);
+  park(0);
+  load_a();
+  advance(pfa);
+  park(1);
+  load_a();
+  advance(pfa);
+  load_b(b0);
+  advance(pfb);
+  load_b(b1);
+  advance(pfb);
   ring_barrier();
+  read_a(af, 0, 0);
+  read_a(af, 0, 1);
 
-  // one stage = { request stage g + 2; MFMAs of stage g; park the slice of g + 2; barrier }.  Slot (g + 2) % 3 was last
-  // read in stage g - 1, which every wave left through that stage's barrier; it is read again in stage g + 2, two
-  // barriers from now.
+  // ---- one stage.  bc: activations of this stage (landed); bp: register set the stage-after-next is requested into;
+  //      sc / sp / sn: ring slots of this stage, of the slice parked now (stage + 2), of the next stage.
+  //   G0 | park slice g + 2 (requested one stage ago), request slice g + 3, fragments i4 = 2, 3 of this stage
+  //   G1 | request the activations of stage g + 2
+  //   G2 | advance the cursors; barrier (publishes the slice parked in this stage; everybody has left slot sp's old
+  //      | reads); fragments i4 = 0, 1 of the NEXT stage (its slice was published by the previous stage's barrier)
+  //   G3 | end of a tile: epilogue
+  // Slot sp = (g + 2) % 3 was last read in stage g - 1 (fragments i4 = 2, 3, before that stage's barrier).
+  auto stage = [&](const float4 (&bc)[4], float4 (&bp)[4], int sc, int sp, int sn) {
+    mfma_group(af, bc[0], 0);
+    SMOS_FENCE();
+    park(sp);
+    load_a();
+    read_a(af, sc, 2);
+    read_a(af, sc, 3);
+    SMOS_FENCE();
+    mfma_group(af, bc[1], 1);
+    SMOS_FENCE();
+    load_b(bp);
+    SMOS_FENCE();
+    mfma_group(af, bc[2], 2);
+    SMOS_FENCE();
+    advance(pfa);
+    advance(pfb);
+    ring_barrier();
+    read_a(af, sn, 0);
+    read_a(af, sn, 1);
+    SMOS_FENCE();
+    mfma_group(af, bc[3], 3);
+    SMOS_FENCE();
+    if (cur.s + 1 == a.nstage) epilogue();
+    advance(cur);
+  };
+
 #pragma unroll 1
   for (int g = 0; g < total; g += 3) {
-    issue(b2, ar);
-    compute(b0, 0);
-    park(ar, 2);
-    ring_barrier();
-    finish_stage();
-    if (g + 1 < total) {
-      issue(b0, ar);
-      compute(b1, 1);
-      park(ar, 0);
-      ring_barrier();
-      finish_stage();
-    }
-    if (g + 2 < total) {
-      issue(b1, ar);
-      compute(b2, 2);
-      park(ar, 1);
-      ring_barrier();
-      finish_stage();
-    }
+    stage(b0, b2, 0, 2, 1);
+    if (g + 1 < total) stage(b1, b0, 1, 0, 2);
+    if (g + 2 < total) stage(b2, b1, 2, 1, 0);
   }
 }
 
@@ -258,7 +300,12 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)3 * 256 * MT * sizeof(float4);
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT>), lds, 256, &ks, "conv_cl")) return rc;
-  const int per_cu = ks.per_cu < 2 ? ks.per_cu : 2;        // two blocks per CU: 2 waves per SIMD, room left for the other stream
+  static const int want_per_cu = [] {                       // tuning knob (tools/ubench_conv.py); default below
+    const char* e = getenv("SMOS_CONV_BLOCKS_PER_CU");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 8 ? v : 2;
+  }();
+  const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;   // default two blocks per CU = 2 waves per SIMD
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_igemm<MT>), dim3(grid), dim3(256), lds, s, a);
