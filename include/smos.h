@@ -240,16 +240,6 @@ int smos_msda_fwd_qp(const float* value, const float* qp, float* out, int64_t N,
 int smos_add_layer_norm(const float* x, const float* res, const float* gamma, const float* beta, float* out, int64_t rows,
                         int64_t C, float eps, smos_stream_t stream);
 
-/* 3x3 / stride 1 / pad 1 convolution, Cin = Cout = C in {32, 64}, channels-last, epilogue fused:
- * out = act(conv(x) + bias [+ res]); act 0 none, 1 ReLU, 2 LeakyReLU(0.01) (csrc/conv3x3.hip; the 3x3 convs of the
- * BasicBlocks, networks/backbone.py:87-102, with BatchNorm folded).  x / res / out are [B, H, W, *] with row pitches in
- * floats (multiples of 4; channel slices of wider buffers are fine); W must be a multiple of 32; bias / res may be NULL.
- * wprep: smos_conv3x3_weight_floats(C) floats in MFMA operand order
- *   wprep[((tap * C/32 + mt) * C/2 + s) * 64 + lane] = w[mt*32 + (lane & 31)][(lane >> 5) * C/2 + s][tap / 3][tap % 3]. */
-int64_t smos_conv3x3_weight_floats(int64_t C);
-int smos_conv3x3_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
-                    float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, int32_t act, smos_stream_t stream);
-
 /* General channels-last convolution on the matrix cores with the epilogue fused (csrc/conv_igemm.hip):
  *   out = act(conv_{KH x KW, stride, pad}(x) + bias [+ res]);  act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
  * Replaces every conv2d -> BatchNorm (folded by the caller) -> ReLU / LeakyReLU (-> + residual -> ReLU) chain of

@@ -44,8 +44,6 @@ SIGNATURES = {
     "smos_stem_zero_rows": [vp, vp, i64, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
-    "smos_conv3x3_weight_floats": [i64],
-    "smos_conv3x3_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
@@ -90,7 +88,6 @@ def load():
         fn.restype = ctypes.c_int
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
     lib.smos_stem_scan_bytes.restype = ctypes.c_int64
-    lib.smos_conv3x3_weight_floats.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p

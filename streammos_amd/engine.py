@@ -147,18 +147,11 @@ class InferenceEngine:
             self.conv_1 = (_cl_w(self.conv_1[0]), self.conv_1[1])
             self.conv_2 = (_cl_w(self.conv_2[0]), self.conv_2[1])
             self.aux = (_cl_w(self.aux[0]), self.aux[1], self.aux[2])
-        # own fused 3x3 conv (csrc/conv3x3.hip) for BasicBlocks.  Alone on the GPU it matches MIOpen's kernel and saves the
-        # separate epilogue pass (tools/ubench_conv3x3.py: 0.065 vs 0.083 ms at 32 ch x 256^2, 0.052 vs 0.062 at 64 ch x
-        # 128^2).  Inside the two-stream step the 32-channel blocks gain (216.5 / 217.2 vs 213.6 / 213.8 scans/s, same box),
-        # the 64-channel ones lose (210.6): their 144 KB of LDS-resident weights allow one block per CU and crowd out the
-        # other stream's kernels.  Default: 32 channels only (SMOS_OWN_CONV=0 disables, SMOS_OWN_CONV=32,64 widens).
-        sel = os.environ.get("SMOS_OWN_CONV", "32")
-        self.own_conv_channels = tuple(int(v) for v in sel.split(",") if v.strip() in ("32", "64"))
-        self.own_conv = len(self.own_conv_channels) > 0
-        for blocks in (self.header_bev, self.header_rv, self.res1_bev, self.res1_rv, self.res2):
-            for p in blocks:
-                if p.kind == "basic" and p.w1.shape[0] in (32, 64) and tuple(p.w1.shape) == tuple(p.w2.shape) == (p.w1.shape[0],) * 2 + (3, 3):
-                    p.w1p, p.w2p = ops.conv3x3_prepare(p.w1), ops.conv3x3_prepare(p.w2)
+        # every 2-D convolution of the channels-last engine runs on the library's own implicit-GEMM kernel with the
+        # epilogue fused (csrc/conv_igemm.hip).  SMOS_OWN_CONV=0 falls back to MIOpen convs + separate epilogue passes
+        # (kept for A/B runs; tools/ubench_conv.py compares the two per layer).
+        self.own_conv = os.environ.get("SMOS_OWN_CONV", "1") != "0"
+        self._wprep = {}
         self._shapes = None
         self._lsi = None
         self._hw = None
@@ -365,40 +358,43 @@ class InferenceEngine:
             return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
-    def _own_conv_for(self, x, p):
-        """BasicBlocks that run on csrc/conv3x3.hip (see the note in __init__)."""
-        if not self.own_conv or getattr(p, "w1p", None) is None:
-            return False
-        b, c, h, w = x.shape
-        return w % 32 == 0 and c in self.own_conv_channels
+    def _conv(self, x, w, bias, act, stride=1, residual=None, out=None):
+        """act(conv(x, w) + bias [+ residual]) for a folded weight w [Cout, Cin, KH, KW] ("same" padding for odd kernels)
+        on channels-last maps: one launch of csrc/conv_igemm.hip; the operand-ordered copy of w is made once per (weight,
+        mt).  With SMOS_OWN_CONV=0: MIOpen conv + the separate bias / activation / residual pass."""
+        cout, cin, kh, kw = w.shape
+        if not self.own_conv or cin % 32 or cout % 32:
+            y = F.conv2d(x, w, None, stride, (kh // 2, kw // 2))
+            if bias is None and act == NONE and residual is None and out is None:
+                return y
+            return ops.bias_act_cl(y, bias, act, out=out if out is not None else y, residual=residual)
+        b, _, h, wd = x.shape
+        ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (wd + 2 * (kw // 2) - kw) // stride + 1
+        mt = ops.conv_mt(cout, b * ho * wo)
+        key = (w.data_ptr(), mt)
+        wp = self._wprep.get(key)
+        if wp is None:
+            wp = self._wprep[key] = ops.conv_prepare(w, mt)
+        return ops.conv_cl(x, wp, bias, act, cout, (kh, kw), stride=stride, mt=mt, residual=residual, out=out)
 
     def _block_cl(self, x, p, out=None):
         if p.kind == "down":
-            a = F.conv2d(x, p.wa, None, p.stride, 1)
-            q = F.conv2d(x, p.wp)
+            a = self._conv(x, p.wa, None, NONE, stride=p.stride)
+            q = self._conv(x, p.wp, None, NONE)
             return ops.downsample_epilogue_cl(a, q, p.bias, p.stride, out=out if out is not None else a)
         if p.kind == "unbalance":
             b, c, h, w = x.shape
             both = ops.empty_cl(b, 2 * c, h, w, x.device)
-            ops.bias_act_cl(F.conv2d(x, p.wa, None, 1, p.pa), p.ba, RELU, out=both[:, :c])
-            ops.bias_act_cl(F.conv2d(x, p.wb, None, 1, p.pb), p.bb, RELU, out=both[:, c:])
-            y = F.conv2d(both, p.wc, None, 1, 1)
-            return ops.bias_act_cl(y, p.bc, RELU, out=out if out is not None else y, residual=x)
-        if self._own_conv_for(x, p):
-            # the library's own 3x3 conv with the epilogue fused (csrc/conv3x3.hip): as fast as MIOpen's kernel for these
-            # shapes, minus the separate bias / ReLU / residual pass
-            y = ops.conv3x3_cl(x, p.w1p, p.b1, RELU)
-            if not p.att:
-                return ops.conv3x3_cl(y, p.w2p, p.b2, RELU, residual=x, out=out)
-        else:
-            y = F.conv2d(x, p.w1, None, 1, 1)
-            ops.bias_act_cl(y, p.b1, RELU, out=y)
-        y2 = F.conv2d(y, p.w2, None, 1, 1)
-        dst = out if out is not None else y2
-        if p.att:
-            need = (y2.shape[2] * y2.shape[3] // 512 + 2) * y2.shape[0] * y2.shape[1]
-            return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self._block_ws(p, need), out=dst)
-        return ops.bias_act_cl(y2, p.b2, RELU, out=dst, residual=x)
+            self._conv(x, p.wa, p.ba, RELU, out=both[:, :c])
+            self._conv(x, p.wb, p.bb, RELU, out=both[:, c:])
+            return self._conv(both, p.wc, p.bc, RELU, residual=x, out=out)
+        y = self._conv(x, p.w1, p.b1, RELU)
+        if not p.att:
+            return self._conv(y, p.w2, p.b2, RELU, residual=x, out=out)
+        y2 = self._conv(y, p.w2, None, NONE)
+        need = (y2.shape[2] * y2.shape[3] // 512 + 2) * y2.shape[0] * y2.shape[1]
+        return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self._block_ws(p, need),
+                                            out=out if out is not None else y2)
 
     def _stage_cl(self, x, blocks, out=None):
         for i, p in enumerate(blocks):
@@ -460,7 +456,7 @@ class InferenceEngine:
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
         k = self.aux[2]
         if self.upconv:
-            y = ops.upconv3x3(F.conv2d(x0cat, self.conv_1a, None, 1, 1), self.conv_1[1],
+            y = ops.upconv3x3(self._conv(x0cat, self.conv_1a, None, NONE), self.conv_1[1],
                               [(x1cat, self.conv_1z[0]), (x2, self.conv_1z[1])], LEAKY)
             size = tuple(x0cat.shape[2:])
 
@@ -476,11 +472,9 @@ class InferenceEngine:
                 aux.append(F.interpolate(head1x1(src, wb), size=size, mode="bilinear", align_corners=True))
         else:
             dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
-            y = F.conv2d(dec_in, self.conv_1[0], None, 1, 1)
-            ops.bias_act_cl(y, self.conv_1[1], LEAKY, out=y)
+            y = self._conv(dec_in, self.conv_1[0], self.conv_1[1], LEAKY)
             aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
-        bev_feat = F.conv2d(y, self.conv_2[0], None, 1, 1)
-        ops.bias_act_cl(bev_feat, self.conv_2[1], LEAKY, out=bev_feat)
+        bev_feat = self._conv(y, self.conv_2[0], self.conv_2[1], LEAKY)
         ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
         return self._point_heads(fuse, aux, k, x2)
 

@@ -420,31 +420,6 @@ def point_head(rows, wprep, m3, out=None):
     return out
 
 
-def conv3x3_prepare(w):
-    """w [C, C, 3, 3] (C in {32, 64}) -> the weight block of smos_conv3x3_cl in MFMA operand order."""
-    c = w.shape[0]
-    if tuple(w.shape) != (c, c, 3, 3) or c not in (32, 64):
-        raise RuntimeError("conv3x3_prepare: expected [C, C, 3, 3] with C in {32, 64}, got %s" % (tuple(w.shape),))
-    wt = w.float().reshape(c // 32, 32, 2, c // 2, 9)                       # [mt, m, h, s, tap]
-    return wt.permute(4, 0, 3, 2, 1).reshape(-1).contiguous()               # [tap, mt, s, h, m] -> lane = h*32 + m
-
-
-def conv3x3_cl(x, wprep, bias, act, residual=None, out=None):
-    """act(conv3x3(x) + bias [+ residual]) for channels-last [B,C,H,W] views (C in {32, 64}, W % 32 == 0), one kernel."""
-    _require_cuda("conv3x3_cl", x, wprep, bias, residual, out)
-    b, c, h, w = x.shape
-    if out is None:
-        out = empty_cl(b, c, h, w, x.device)
-    lib = _lib.load()
-    with torch.cuda.device(x.device), profiling.span("conv3x3_cl[%dx%dx%dx%d]" % (b, c, h, w)):
-        rc = lib.smos_conv3x3_cl(x.data_ptr(), _cl("conv3x3_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                 residual.data_ptr() if residual is not None else None,
-                                 _cl("conv3x3_cl", residual) if residual is not None else 0, out.data_ptr(), _cl("conv3x3_cl", out),
-                                 b, h, w, c, int(act), _stream(x))
-    _lib.check(rc, "smos_conv3x3_cl")
-    return out
-
-
 def conv_prepare(w, mt):
     """w [Cout, Cin, KH, KW] (BatchNorm folded) -> the weight block of smos_conv_cl in MFMA operand order for `mt`
     32-channel output blocks per wave (include/smos.h): [cout tile][stage = (ky, kx, cin chunk)][k-step / 4][mt][lane][k-step % 4]

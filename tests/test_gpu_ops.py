@@ -335,27 +335,6 @@ def test_msda_fwd_qp_equals_module_formulation(hw, m, pnt):
     assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("c,hw,act,with_res", [(32, (40, 64), 1, False), (64, (24, 96), 1, True), (32, (16, 1024), 0, False),
-                                               (64, (7, 32), 2, True)])
-def test_conv3x3_cl_against_float64(c, hw, act, with_res):
-    """The library's own fused 3x3 conv (MFMA implicit GEMM, bias + act + residual in the epilogue) against conv2d in
-    float64, on channel slices of wider channels-last buffers (pitch 2C)."""
-    import torch.nn.functional as F
-    gen = torch.Generator(device="cpu").manual_seed(59)
-    b, (h, w) = 2, hw
-    wide = torch.randn((b, h, w, 2 * c), generator=gen).to(DEV)
-    x = wide[..., :c].permute(0, 3, 1, 2)                       # channel slice, pitch 2C
-    res = wide[..., c:].permute(0, 3, 1, 2) if with_res else None
-    wt = (torch.randn((c, c, 3, 3), generator=gen) * 0.1).to(DEV)
-    bias = torch.randn(c, generator=gen).to(DEV)
-    got = ops.conv3x3_cl(x, ops.conv3x3_prepare(wt), bias, act, residual=res)
-    want = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)
-    if with_res:
-        want = want + res.double()
-    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.01) if act == 2 else want)
-    assert (got.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
-
-
 @pytest.mark.parametrize("c", [64, 128, 512])
 def test_add_layer_norm_against_torch(c):
     import torch.nn.functional as F
