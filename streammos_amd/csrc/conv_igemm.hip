@@ -8,19 +8,23 @@
 // output pixels of one image row on the column, v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered fmaf chain).
 //
 //   work item  = 4 output rows x 32 columns x (32 * MT) output channels; one block (4 waves) per item, one row per wave;
-//                blocks are persistent and walk the items in a fixed order, cout tile fastest.
+//                blocks are persistent and own a contiguous range of items (cout tile fastest).
 //   stage      = 32 input channels of one tap (16 k-steps): 16 * MT MFMAs per wave.  The K loop of a tile is a sequence
-//                of KH * KW * Cin / 32 stages, and the stages of consecutive tiles form ONE stream: the operand prefetch
-//                runs two stages ahead straight across tile boundaries, so a wave's pipeline never drains.
-//   B operand  = activations, read directly from global memory (L1 / L2 absorb the tap re-reads): lane (p, h) loads four
-//                float4 = channels 8 j + 4 h + (0..3) of the stage's 32, zeros outside the image; three named register
-//                sets rotate (computing / landed / in flight).
-//   A operand  = weights, STREAMED through a three-slot LDS ring (4 * MT KB per stage) instead of being resident: the
-//                block's 256 threads fetch the slice of stage g + 2 at the top of stage g (one float4 each per MT), park it
-//                in registers during the stage's MFMAs and store it to the ring afterwards; one barrier per stage.  A lane
-//                reads its fragment as float4 = four consecutive k-steps (host-side operand order, ops.conv_prepare).
-//                12 * MT KB of LDS per block: several blocks per CU coexist with the other HIP stream's kernels (the first
-//                version, csrc/conv3x3.hip, kept 144 KB resident at C = 64 and was crowded out of the pipeline).
+//                of KH * KW * Cin / 32 stages, and the stages of consecutive tiles form ONE stream: operand requests run
+//                three stages ahead straight across tile boundaries, so a wave's pipeline never drains.
+//   B operand  = activations, read directly from global memory (L1 / L2 absorb the tap re-reads) through a buffer
+//                descriptor: lane (p, h) loads four float4 = channels 8 j + 4 h + (0..3) of the stage's 32; lanes outside
+//                the image use an offset past the end and read zeros.  Four named register sets rotate.
+//   A operand  = weights, STREAMED through a four-slot LDS ring (4 * MT KB per stage) instead of being resident: the
+//                block's 256 threads request the slice of stage g + 3 in stage g (one float4 each per MT), keep it in
+//                registers for two stages and store it to the ring in stage g + 2; one barrier per stage publishes it.
+//                A lane reads its fragment as float4 = four consecutive k-steps (host-side operand order, ops.conv_prepare).
+//                16 * MT KB of LDS per block: several blocks per CU coexist with the other HIP stream's kernels (the first
+//                version of an own conv kept 144 KB of weights resident at C = 64 and was crowded out of the pipeline).
+//   waits      = vmcnt retires in order, so a wait for one load is a wait for every older one: every operand is
+//                requested >= 2 stages before its first use and nothing young is ever waited for -- in particular the
+//                epilogue issues no load (bias lives in LDS, the residual tile is requested one stage early), otherwise it
+//                would drain the whole prefetch once per tile (measured with in-kernel stamps: 19-23 % of a wave's time).
 //   epilogue   = out = act(acc + bias [+ residual]) from the accumulators, 16-byte stores (lane (p, h), register r <->
 //                channel 32 mt + 8 (r >> 2) + 4 h + (r & 3)); inputs, residual and output may be channel slices of
 //                wider channels-last buffers (row pitches).
@@ -48,15 +52,17 @@ struct ConvArgs {
   int hq, xt;          // ceil(Ho / 4), ceil(Wo / 32)
   int n_items;         // B * hq * xt * nct
   float slope;         // activation: max(v, 0) + slope * min(v, 0) -- 1 none, 0 ReLU, 0.01 LeakyReLU
+#ifdef SMOS_CONV_STAMPS
+  unsigned long long* stamps;
+#endif
   int x_bytes;         // B * H * W * xp * 4 (< 2^31: lanes outside the image use offset 2^31)
-  int r_bytes, o_bytes, cout_bytes;   // B * Ho * Wo * rp * 4, B * Ho * Wo * op * 4, Cout * 4
+  int r_bytes, o_bytes, cout;   // B * Ho * Wo * rp * 4, B * Ho * Wo * op * 4, Cout
 };
 
-
 // Ring barrier.  __syncthreads() would also do, but its workgroup fence makes hipcc wait vmcnt(0) -- draining the operand
-// prefetch of the next two stages once per stage.  Only LDS traffic has to be ordered here: every wave drains its own LDS
-// queue (ring stores landed, fragment reads returned), then the barrier.  The "memory" clobbers keep the compiler from
-// moving ring accesses across it.
+// prefetch once per stage.  Only LDS traffic has to be ordered here: every wave drains its own LDS queue (ring stores
+// landed, fragment reads returned), then the barrier.  The "memory" clobbers keep the compiler from moving ring accesses
+// across it.
 __device__ __forceinline__ void ring_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -73,105 +79,135 @@ __device__ __forceinline__ void ring_barrier() {
     __builtin_amdgcn_sched_barrier(0); /* machine scheduler: nothing crosses, MFMAs included */ \
   } while (0)
 
-struct ConvCursor {    // a position in the block's stream of stages: item (= 4 tiles) and tap / channel chunk inside it
-  int it, s, dy, dx, ch;
-  int ct, xt, yq, b;
+// Diagnostic build only (-DSMOS_CONV_STAMPS, tools/conv_stamps.py): cycles a wave spends in each segment of the stage,
+// summed over its stages and written to a buffer of their own.  The shipped library contains no stamp.
+#ifdef SMOS_CONV_STAMPS
+#define SMOS_STAMP(k)                                                                              \
+  do {                                                                                             \
+    unsigned long long t_;                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    stamp_sum[k] += t_ - stamp_last;                                                               \
+    stamp_last = t_;                                                                               \
+  } while (0)
+#else
+#define SMOS_STAMP(k)
+#endif
+
+struct ConvTile {      // where a wave's 32-pixel row segment lies (everything scalar; recomputed once per tile)
+  int b, y, x0, ct;
+  bool valid;
 };
 
-template <int MT>
+template <int MT, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 3 slots x 256 * MT float4
+  extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 * MT float4, then Cout bias floats
   constexpr int kSlot = 256 * MT;
+  float* bias_lds = reinterpret_cast<float*>(ring + 4 * kSlot);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
-  // a block owns a contiguous range of items, so that the cursors advance by carries instead of divisions
+  // a block owns a contiguous range of items (cout tile fastest, so the weight slices of its stages are one cyclic
+  // sequence).  Blocks b, b + 8, b + 16 .. share an XCD and its L2 (dispatch is round-robin over the 8 XCDs): they get
+  // neighbouring ranges, so that the rows one block reads as halo are the rows its neighbour reads as centre (speed only).
   const int per_block = (a.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int first = (int)blockIdx.x * per_block;
+  const int nb = (int)gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = (int)blockIdx.x & 7;
+  const int lblock = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+  const int first = lblock * per_block;
   const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
   const int total = iters * a.nstage;
   if (total <= 0) return;
+  for (int i = tid; i < a.cout; i += 256) bias_lds[i] = a.bias ? a.bias[i] : 0.0f;      // published by the prologue's barrier
 
-  auto cursor_at_first = [&]() {
-    ConvCursor c;
-    c.it = c.s = c.dy = c.dx = c.ch = 0;
-    c.ct = first % a.nct;
-    int u = first / a.nct;
-    c.xt = u % a.xt;
+  // Bookkeeping is kept off the per-stage path: the scalar unit is shared by the CU's waves, and a hundred cursor
+  // instructions per stage cost more wave time than the stage's 16 MFMAs (in-kernel stamps).  Per stage: three counters and
+  // one running offset; per TILE (a rare, wave-uniform branch at the end of a stage): the divisions that locate it.
+  auto tile_of = [&](int it) {
+    ConvTile t;
+    t.valid = it < iters;
+    const int q = t.valid ? first + it : first;
+    t.ct = q % a.nct;
+    int u = q / a.nct;
+    t.x0 = (u % a.xt) * 32;
     u /= a.xt;
-    c.yq = u % a.hq;
-    c.b = u / a.hq;
-    return c;
-  };
-  // one stage further: channel chunk fastest, then the tap column, the tap row, then the next item (cout tile fastest).
-  // Selects only -- the stage body stays one basic block.
-  auto advance = [&](ConvCursor& c) {
-    const bool ch_wrap = c.ch + 1 == a.nch;
-    c.ch = ch_wrap ? 0 : c.ch + 1;
-    const bool dx_wrap = ch_wrap && c.dx + 1 == a.KW;
-    c.dx = dx_wrap ? 0 : (ch_wrap ? c.dx + 1 : c.dx);
-    c.dy = dx_wrap ? c.dy + 1 : c.dy;
-    const bool tile_wrap = c.s + 1 == a.nstage;
-    c.s = tile_wrap ? 0 : c.s + 1;
-    c.dy = tile_wrap ? 0 : c.dy;
-    c.it += tile_wrap ? 1 : 0;
-    const bool ct_wrap = tile_wrap && c.ct + 1 == a.nct;
-    c.ct = ct_wrap ? 0 : (tile_wrap ? c.ct + 1 : c.ct);
-    const bool xt_wrap = ct_wrap && c.xt + 1 == a.xt;
-    c.xt = xt_wrap ? 0 : (ct_wrap ? c.xt + 1 : c.xt);
-    const bool yq_wrap = xt_wrap && c.yq + 1 == a.hq;
-    c.yq = yq_wrap ? 0 : (xt_wrap ? c.yq + 1 : c.yq);
-    c.b += yq_wrap ? 1 : 0;
+    t.y = (u % a.hq) * 4 + wave;
+    t.b = u / a.hq;
+    t.valid = t.valid & (t.y < a.Ho);
+    return t;
   };
 
-  // activations / bias / residual / output as raw buffers: a missing operand is a zero-length buffer (reads as zero); a
-  // lane outside the image gets an offset past the end (loads return zero = the convolution's padding, stores are
-  // dropped).  No load sits under a lane-dependent branch -- hipcc would stop counting and wait vmcnt(0) at the next use,
-  // draining the prefetch every stage.
+  // activations / residual / output as raw buffers: a lane outside the image gets an offset past the end (loads return
+  // zero = the convolution's padding, stores are dropped).  No load sits under a lane-dependent branch -- hipcc would stop
+  // counting and wait vmcnt(0) at the next use.
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t bsrd =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
 
-  ConvCursor pfb = cursor_at_first();      // activations: stage being requested (two ahead of the one being computed)
-  ConvCursor pfa = cursor_at_first();      // weights: slice being requested (three ahead)
-  ConvCursor cur = cursor_at_first();      // stage being computed
-
+  // ---- activation requests (three stages ahead): position inside the tile = counters + a running element offset ----
+  const int xp = (int)a.xp;
+  const int d_dx = xp - (a.nch - 1) * 32;                              // next tap column: back to channel chunk 0
+  const int d_dy = (a.W - (a.KW - 1)) * xp - (a.nch - 1) * 32;         // next tap row: back to tap column 0
+  int pb_it = 0, pb_left = a.nstage, pb_ch = 0, pb_dx = 0, pb_dy = 0, pb_delta = 0;
+  int pb_y0, pb_xs, pb_base;      // first input row (scalar), first input column (per lane), element offset of (row, column, 4 h)
+  bool pb_valid;
+  auto locate_b = [&]() {
+    const ConvTile t = tile_of(pb_it);
+    pb_valid = t.valid;
+    pb_y0 = t.y * a.S - a.PH;
+    pb_xs = (t.x0 + p) * a.S - a.PW;
+    pb_base = ((t.b * a.H + pb_y0) * a.W + pb_xs) * xp + 4 * h;
+  };
+  locate_b();
   auto load_b = [&](float4 (&bset)[4]) {
-    const int y = pfb.yq * 4 + wave;
-    const int yy = y * a.S - a.PH + pfb.dy;
-    const int xx = (pfb.xt * 32 + p) * a.S - a.PW + pfb.dx;
     // bitwise: a short-circuit && becomes a branch and splits the stage body
-    const bool ok = (pfb.it < iters) & (y < a.Ho) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W);
-    const unsigned off = (unsigned)(((pfb.b * a.H + yy) * a.W + xx) * (int)a.xp + pfb.ch * 32 + 4 * h) * 4u;
-    const unsigned voff = ok ? off : 0x80000000u;
+    const bool ok = pb_valid & ((unsigned)(pb_y0 + pb_dy) < (unsigned)a.H) & ((unsigned)(pb_xs + pb_dx) < (unsigned)a.W);
+    const unsigned voff = ok ? (unsigned)(pb_base + pb_delta) * 4u : 0x80000000u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + 32u * j, 0, 0);
       bset[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
-  // the weight slice in flight: named registers (an array here ends up in scratch memory for MT > 1)
-  float4 ar0, ar1, ar2, ar3;
-  auto load_a = [&]() {
-    const int slice = pfa.it < iters ? pfa.ct * a.nstage + pfa.s : 0;      // past the last tile: any valid slice
-    const float4* wsrc = a.w + (int64_t)slice * kSlot + tid;
-    ar0 = wsrc[0];
-    if constexpr (MT > 1) ar1 = wsrc[256];
-    if constexpr (MT > 2) {
-      ar2 = wsrc[512];
-      ar3 = wsrc[768];
-    }
+  auto advance_b = [&]() {          // channel chunk fastest, then the tap column, then the tap row; selects only
+    const bool ch_wrap = pb_ch + 1 == a.nch;
+    const bool dx_wrap = ch_wrap & (pb_dx + 1 == a.KW);
+    pb_delta += ch_wrap ? (dx_wrap ? d_dy : d_dx) : 32;
+    pb_ch = ch_wrap ? 0 : pb_ch + 1;
+    pb_dx = dx_wrap ? 0 : pb_dx + (ch_wrap ? 1 : 0);
+    pb_dy += dx_wrap ? 1 : 0;
+    --pb_left;
   };
-  auto park = [&](int slot) {
-    float4* dst = ring + slot * kSlot + tid;
-    dst[0] = ar0;
-    if constexpr (MT > 1) dst[256] = ar1;
+  auto next_tile_b = [&]() {        // rare path
+    pb_left = a.nstage;
+    pb_ch = pb_dx = pb_dy = pb_delta = 0;
+    ++pb_it;
+    locate_b();
+  };
+
+  // ---- weight requests (three stages ahead): the slices of consecutive stages are consecutive, cyclically ----
+  const int n_slices = a.nct * a.nstage;
+  int pa_slice = (first % a.nct) * a.nstage, pa_g = 0;
+  // weight slices in flight: two sets of named registers (arrays here end up in scratch memory for MT > 1)
+  auto load_a = [&](float4& r0, float4& r1, float4& r2, float4& r3) {
+    const float4* wsrc = a.w + (int64_t)(pa_g < total ? pa_slice : 0) * kSlot + tid;      // past the end: any valid slice
+    r0 = wsrc[0];
+    if constexpr (MT > 1) r1 = wsrc[256];
     if constexpr (MT > 2) {
-      dst[512] = ar2;
-      dst[768] = ar3;
+      r2 = wsrc[512];
+      r3 = wsrc[768];
+    }
+    ++pa_g;
+    pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;
+  };
+  auto park = [&](int slot, const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+    float4* dst = ring + slot * kSlot + tid;
+    dst[0] = r0;
+    if constexpr (MT > 1) dst[256] = r1;
+    if constexpr (MT > 2) {
+      dst[512] = r2;
+      dst[768] = r3;
     }
   };
   auto read_a = [&](float4 (&af)[4][MT], int slot, int i4) {
@@ -196,29 +232,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].w, bv.w, acc[mt], 0, 0, 0);
   };
 
+  // ---- the stage being computed: a countdown to the end of its tile; the tile itself is located when it is needed ----
+  int c_it = 0, c_left = a.nstage;
+  // The residual tile is requested one stage before the stage that ends the tile (a wave-uniform branch; vmcnt retires in
+  // order, so requested any later the epilogue's wait for it would drain the whole operand prefetch).
+  u32x4 rr[RES ? 4 * MT : 1];
+  auto request_residual = [&]() {
+    if constexpr (RES) {
+      const ConvTile t = tile_of(c_it);
+      const int x = t.x0 + p;
+      const bool want = t.valid & (x < a.Wo);
+      const int pix = (t.b * a.Ho + t.y) * a.Wo + x;
+      const unsigned roff = want ? (unsigned)(pix * (int)a.rp + t.ct * 32 * MT + 4 * h) * 4u : 0x80000000u;
+#pragma unroll
+      for (int k = 0; k < 4 * MT; ++k) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, roff + 32u * k, 0, 0);
+    }
+  };
+
   auto epilogue = [&]() {
-    const int y = cur.yq * 4 + wave, x = cur.xt * 32 + p;
-    const bool store = (y < a.Ho) & (x < a.Wo);
-    const int pix = (cur.b * a.Ho + y) * a.Wo + x;
-    const int cbase = cur.ct * 32 * MT + 4 * h;
-    const unsigned boff = (unsigned)cbase * 4u;
-    const unsigned roff = store ? (unsigned)(pix * (int)a.rp + cbase) * 4u : 0x80000000u;
+    const ConvTile t = tile_of(c_it);
+    const int x = t.x0 + p;
+    const bool store = t.valid & (x < a.Wo);
+    const int pix = (t.b * a.Ho + t.y) * a.Wo + x;
+    const int cbase = t.ct * 32 * MT + 4 * h;
     const unsigned ooff = store ? (unsigned)(pix * (int)a.op + cbase) * 4u : 0x80000000u;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      u32x4 bv[4], rv[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bv[g] = __builtin_amdgcn_raw_buffer_load_b128(bsrd, boff + 4u * (mt * 32 + 8 * g), 0, 0);
-        rv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, roff + 4u * (mt * 32 + 8 * g), 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_lds + cbase + mt * 32 + 8 * g);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          float v = acc[mt][4 * g + c] + __uint_as_float(bv[g][c]);
-          v += __uint_as_float(rv[g][c]);
+          float v = acc[mt][4 * g + c] + bb[c];
+          if constexpr (RES) v += __uint_as_float(rr[4 * mt + g][c]);
           // none / ReLU / LeakyReLU without a branch: max(v, 0) + slope * min(v, 0), slope = 1 / 0 / 0.01 (one of the two
           // terms is always zero, so this is exact)
           o[c] = __builtin_fmaf(a.slope, fminf(v, 0.f), fmaxf(v, 0.f));
@@ -231,75 +279,105 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     }
   };
 
-  float4 b0[4], b1[4], b2[4], af[4][MT];
-  // ---- prologue: slices 0 and 1 in the ring, slice 2 in registers, activations of stages 0 and 1 requested ----
-  load_a();
-  advance(pfa);
-  park(0);
-  load_a();
-  advance(pfa);
-  park(1);
-  load_a();
-  advance(pfa);
+#ifdef SMOS_CONV_STAMPS
+  unsigned long long stamp_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
+  float4 b0[4], b1[4], b2[4], b3[4], af[4][MT];
+  float4 ae0, ae1, ae2, ae3, ao0, ao1, ao2, ao3;       // weight slices of even / odd stages on their way to the ring
+  // ---- prologue: slice 0 in the ring, slices 1 and 2 in registers, activations of stages 0, 1 and 2 requested ----
+  // (requests in the order of the steady state -- weights, then activations, stage by stage -- so that the in-flight
+  // picture hipcc's wait-count pass sees at the loop head is the same from the prologue and from the back edge)
+  load_a(ae0, ae1, ae2, ae3);
   load_b(b0);
-  advance(pfb);
+  advance_b();
+  if (pb_left == 0) next_tile_b();
+  park(0, ae0, ae1, ae2, ae3);
+  load_a(ao0, ao1, ao2, ao3);
   load_b(b1);
-  advance(pfb);
+  advance_b();
+  if (pb_left == 0) next_tile_b();
+  load_a(ae0, ae1, ae2, ae3);
+  load_b(b2);
+  advance_b();
+  if (pb_left == 0) next_tile_b();
+  if (RES && c_left == 1) request_residual();
   ring_barrier();
   read_a(af, 0, 0);
   read_a(af, 0, 1);
 
-  // ---- one stage.  bc: activations of this stage (landed); bp: register set the stage-after-next is requested into;
-  //      sc / sp / sn: ring slots of this stage, of the slice parked now (stage + 2), of the next stage.
-  //   G0 | park slice g + 2 (requested one stage ago), request slice g + 3, fragments i4 = 2, 3 of this stage
-  //   G1 | request the activations of stage g + 2
-  //   G2 | advance the cursors; barrier (publishes the slice parked in this stage; everybody has left slot sp's old
-  //      | reads); fragments i4 = 0, 1 of the NEXT stage (its slice was published by the previous stage's barrier)
-  //   G3 | end of a tile: epilogue
-  // Slot sp = (g + 2) % 3 was last read in stage g - 1 (fragments i4 = 2, 3, before that stage's barrier).
-  auto stage = [&](const float4 (&bc)[4], float4 (&bp)[4], int sc, int sp, int sn) {
-    mfma_group(af, bc[0], 0);
-    SMOS_FENCE();
-    park(sp);
-    load_a();
-    read_a(af, sc, 2);
-    read_a(af, sc, 3);
-    SMOS_FENCE();
-    mfma_group(af, bc[1], 1);
-    SMOS_FENCE();
-    load_b(bp);
-    SMOS_FENCE();
-    mfma_group(af, bc[2], 2);
-    SMOS_FENCE();
-    advance(pfa);
-    advance(pfb);
-    ring_barrier();
-    read_a(af, sn, 0);
-    read_a(af, sn, 1);
-    SMOS_FENCE();
-    mfma_group(af, bc[3], 3);
-    SMOS_FENCE();
-    if (cur.s + 1 == a.nstage) epilogue();
-    advance(cur);
-  };
+  // ---- one stage g.  bc: activations of this stage (landed); bp: register set stage g + 3 is requested into;
+  //      sc / sn: ring slots of this stage and of the next; (n0..n3): registers holding slice g + 1 (requested two stages ago).
+  //   G0 | park slice g + 1, request slice g + 3 into the same registers, fragments i4 = 2, 3 of this stage
+  //   G1 | request the activations of stage g + 3
+  //   G2 | step the request position; barrier (publishes slice g + 1); fragments i4 = 0, 1 of the next stage
+  //   G3 | rare branches: end of a tile (epilogue), residual request for a tile about to end, next tile of the requests
+  // Slot sn = (g + 1) % 4 was last read in stage g - 3.
+#define SMOS_STAGE(bc, bp, sc, sn, n0, n1, n2, n3) \
+  do {                                             \
+    SMOS_STAMP(8);                                 \
+    mfma_group(af, bc[0], 0);                      \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(0);                                 \
+    park(sn, n0, n1, n2, n3);                      \
+    load_a(n0, n1, n2, n3);                        \
+    read_a(af, sc, 2);                             \
+    read_a(af, sc, 3);                             \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(1);                                 \
+    mfma_group(af, bc[1], 1);                      \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(2);                                 \
+    load_b(bp);                                    \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(3);                                 \
+    mfma_group(af, bc[2], 2);                      \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(4);                                 \
+    advance_b();                                   \
+    ring_barrier();                                \
+    read_a(af, sn, 0);                             \
+    read_a(af, sn, 1);                             \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(5);                                 \
+    mfma_group(af, bc[3], 3);                      \
+    SMOS_FENCE();                                  \
+    SMOS_STAMP(6);                                 \
+    if (--c_left == 0) {                           \
+      epilogue();                                  \
+      c_left = a.nstage;                           \
+      ++c_it;                                      \
+    }                                              \
+    if (RES && c_left == 1) request_residual();    \
+    if (pb_left == 0) next_tile_b();               \
+    SMOS_STAMP(7);                                 \
+  } while (0)
 
+#ifdef SMOS_CONV_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 #pragma unroll 1
-  for (int g = 0; g < total; g += 3) {
-    stage(b0, b2, 0, 2, 1);
-    if (g + 1 < total) stage(b1, b0, 1, 0, 2);
-    if (g + 2 < total) stage(b2, b1, 2, 1, 0);
+  for (int g = 0; g < total; g += 4) {
+    SMOS_STAGE(b0, b3, 0, 1, ao0, ao1, ao2, ao3);
+    if (g + 1 < total) SMOS_STAGE(b1, b0, 1, 2, ae0, ae1, ae2, ae3);
+    if (g + 2 < total) SMOS_STAGE(b2, b1, 2, 3, ao0, ao1, ao2, ao3);
+    if (g + 3 < total) SMOS_STAGE(b3, b2, 3, 0, ae0, ae1, ae2, ae3);
   }
+#ifdef SMOS_CONV_STAMPS
+  if (a.stamps && lane == 0)
+    for (int k = 0; k < 9; ++k) a.stamps[((int64_t)blockIdx.x * 4 + wave) * 9 + k] = stamp_sum[k];
+#endif
 }
 
 }  // namespace smos
 
 using namespace smos;
 
-template <int MT>
+template <int MT, bool RES>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)3 * 256 * MT * sizeof(float4);
+  const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 3) / 4 * 4) * sizeof(float);
   KernelSetup ks;
-  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT>), lds, 256, &ks, "conv_cl")) return rc;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES>), 4 * 256 * MT * sizeof(float4) + 4096, 256, &ks, "conv_cl"))
+    return rc;
   static const int want_per_cu = [] {                       // tuning knob (tools/ubench_conv.py); default below
     const char* e = getenv("SMOS_CONV_BLOCKS_PER_CU");
     const int v = e ? atoi(e) : 0;
@@ -308,7 +386,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;   // default two blocks per CU = 2 waves per SIMD
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
-  hipLaunchKernelGGL((conv_igemm<MT>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm<MT, RES>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_cl");
 }
 
@@ -324,7 +402,7 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
   SMOS_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && (stride == 1 || stride == 2) && pad_h >= 0 && pad_w >= 0 &&
                    act >= 0 && act <= 2, "conv_cl: kernel up to 7 x 7, stride 1 or 2");
   const int64_t Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
-  SMOS_REQUIRE(Ho > 0 && Wo > 0, "conv_cl: empty output");
+  SMOS_REQUIRE(Ho > 0 && Wo > 0 && Cout <= 1024, "conv_cl: empty output / more than 1024 output channels");
   SMOS_REQUIRE(x && wprep && out && x_pitch >= Cin && out_pitch >= Cout && x_pitch % 4 == 0 && out_pitch % 4 == 0 &&
                    (!res || (res_pitch >= Cout && res_pitch % 4 == 0)), "conv_cl: null pointer / bad pitch");
   SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
@@ -343,10 +421,20 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
   a.hq = (int)hq; a.xt = (int)xt; a.n_items = (int)(B * hq * xt * nct);
   a.slope = act == 0 ? 1.0f : act == 1 ? 0.0f : 0.01f;
   a.x_bytes = (int)(B * H * W * x_pitch * 4);
+#ifdef SMOS_CONV_STAMPS
+  {
+    const char* e = getenv("SMOS_CONV_STAMP_PTR");      // device buffer of 4 * 9 * grid uint64, set by the diagnostic script
+    a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+  }
+#endif
   a.r_bytes = res ? (int)(B * Ho * Wo * res_pitch * 4) : 0;
   a.o_bytes = (int)(B * Ho * Wo * out_pitch * 4);
-  a.cout_bytes = (int)(Cout * 4);
-  if (mt == 1) return launch_conv<1>(a, (hipStream_t)stream);
-  if (mt == 2) return launch_conv<2>(a, (hipStream_t)stream);
-  return launch_conv<4>(a, (hipStream_t)stream);
+  a.cout = (int)Cout;
+  if (res) {
+    SMOS_REQUIRE(mt <= 2, "conv_cl: a residual input needs mt <= 2 (register budget)");
+    return mt == 1 ? launch_conv<1, true>(a, (hipStream_t)stream) : launch_conv<2, true>(a, (hipStream_t)stream);
+  }
+  if (mt == 1) return launch_conv<1, false>(a, (hipStream_t)stream);
+  if (mt == 2) return launch_conv<2, false>(a, (hipStream_t)stream);
+  return launch_conv<4, false>(a, (hipStream_t)stream);
 }
