@@ -370,7 +370,7 @@ class InferenceEngine:
             return ops.bias_act_cl(y, bias, act, out=out if out is not None else y, residual=residual)
         b, _, h, wd = x.shape
         ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (wd + 2 * (kw // 2) - kw) // stride + 1
-        mt = ops.conv_mt(cout, b * ho * wo)
+        mt = ops.conv_mt(cout, b * ho * wo, residual is not None)
         key = (w.data_ptr(), mt)
         wp = self._wprep.get(key)
         if wp is None:

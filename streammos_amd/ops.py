@@ -434,11 +434,12 @@ def conv_prepare(w, mt):
     return v.reshape(-1).contiguous()
 
 
-def conv_mt(cout, n_pixels):
+def conv_mt(cout, n_pixels, residual=False):
     """Output blocks per wave for smos_conv_cl: wider waves re-use each activation load more often, narrower ones give
-    more wave tiles; aim at >= 2 waves for each of the 1024 SIMDs."""
+    more wave tiles; aim at >= 2 waves for each of the 1024 SIMDs.  With a residual input the kernel holds the residual
+    tile in registers, which limits it to mt <= 2."""
     tiles32 = (n_pixels + 31) // 32
-    for mt in (4, 2, 1):
+    for mt in ((2, 1) if residual else (4, 2, 1)):
         if cout % (32 * mt) == 0 and tiles32 * (cout // (32 * mt)) >= 2048:
             return mt
     return 1
