@@ -75,7 +75,7 @@ def algorithmic_bytes(label, ctx=None):
         res = geo["b"] * geo["cout"] * geo["ho"] * geo["wo"] if geo["res"] else 0
         return 4 * (geo["b"] * geo["cin"] * geo["h"] * geo["w"] + geo["b"] * geo["cout"] * geo["ho"] * geo["wo"] + res +
                     geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"])
-    if name in ("stem_gemm", "stem_epilogue", "stem_mark+compact"):
+    if name in ("stem_gemm", "stem_epilogue", "stem_mark+scan"):
         # sparse DownSample2D 192 -> 32, stride 2 on the occupied cells: rows in (gemm), half-resolution map out (epilogue)
         b, h, w, cin = (int(v) for v in dims.split("x"))
         rows = ctx.get("stem_rows", b * h * w)
@@ -330,7 +330,7 @@ def main():
             # outside the timed region): rows per launch of the compact scatter target / the sparse first stage
             from streammos_amd import ops as _ops
             metas = [_ops.stem_plan(d["pcds_coord"], *eng.bev_hw).meta.cpu().numpy() for d, _ in dev_frames]
-            stem_class_rows = tuple(float(np.mean([m[c] for m in metas])) for c in range(4))
+            stem_class_rows = tuple(float(np.mean([m[8 + c] - m[4 + c] for m in metas])) for c in range(4))
             ctx["stem_rows"] = float(np.mean([m[11] for m in metas]))
         roof = None
         if dominant and dominant in timed:
@@ -374,7 +374,7 @@ def main():
             rows = torch.empty((bs, n, 192), dtype=torch.float32, device=device)
             compact = eng.sparse_stem and eng.stem_w is not None        # the form the engine launches (engine._encode_cl)
             if compact:
-                plan = _ops.stem_plan(d0["pcds_coord"], *eng.bev_hw)
+                plan = _ops.stem_plan(d0["pcds_coord"], *eng.bev_hw, row_floats=t * 64)
             else:
                 bev = torch.empty((bs,) + tuple(eng.bev_hw) + (t * 64,), dtype=torch.float32, device=device)
             torch.cuda.synchronize()

@@ -202,11 +202,14 @@ int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, cons
 /* Sparse DownSample2D on the input grid (networks/backbone.py:136-159 as used by header_bev[0],
  * multi_view_encoder.py:340-347): see csrc/stem.hip.  All buffers are device memory owned by the caller; no call reads
  * anything back to the host (row counts stay in `meta`), so the sequence is graph-capturable.
- *   smos_stem_mark    flags (int32 [4, B, H/2, W/2], caller zero-fills; index = parity class (y&1)*2+(x&1), sample,
- *                     y>>1, x>>1) <- 1 for every cell a point of coord [B, T, N, K] falls into.
- *   smos_stem_compact scan <- exclusive prefix sum of flags (scan_ws: smos_stem_scan_bytes(B*H*W) bytes of scratch);
- *                     row_cell[row] <- natural cell id (b*H + y)*W + x; row_of [B,H,W] <- row id or -1;
- *                     meta (12 x int32): [0..3] rows per class, [4..7] first row of each class.
+ *   smos_stem_mark    flags (int32 [4, B, H/2, W/2]; index = parity class (y&1)*2+(x&1), sample, y>>1, x>>1) <- 1 for
+ *                     every cell a point of coord [B, T, N, K] falls into.  flags must be all zero on entry (zero it once;
+ *                     smos_stem_scan leaves it all zero again).  Also re-arms scan_state (uint64
+ *                     [smos_stem_scan_state_words(B*H*W)]) for the smos_stem_scan call that follows on the stream.
+ *   smos_stem_scan    one pass over the flags: row_cell[row] <- natural cell id (b*H + y)*W + x; row_of [B,H,W] <- row id
+ *                     or -1; meta (12 x int32): [4..7] first row of each class, [8..11] one past its last row (meta[11] =
+ *                     number of rows); flags cleared; if rows != NULL, rows[0 .. meta[11]) (row_floats floats each: the
+ *                     compact table of smos_pointnet_scatter_rows) zero-filled.
  *   smos_stem_gemm    y4[cls] (device, capacity B*(H/2)*(W/2) rows of (taps+1)*Cout floats; taps = 1,2,2,4) <-
  *                     occupied rows of bev [B*H*W, Cin] times the class weights; with row_cell == NULL, bev is the
  *                     compact row table itself (row r of the table = global row r).  wprep4[cls]: weights of the class in
@@ -216,14 +219,11 @@ int smos_pointnet_scatter(const float* xyzi, const float* coord, int32_t K, cons
  *   smos_stem_epilogue out[b,ho,wo,c] <- relu(sum_taps Y[cell][slot][c] + max_window(occupied ? Y[cell][q][c] : 0) +
  *                     bias[c]); out is channels-last [B, H/2, W/2, *] with row pitch out_pitch; C must be 32.
  * y4 / wprep4 are HOST arrays of 4 device pointers. */
+int64_t smos_stem_scan_state_words(int64_t cells);
 int smos_stem_mark(const float* coord, int32_t K, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t* flags,
-                   smos_stream_t stream);
-int64_t smos_stem_scan_bytes(int64_t cells);
-int smos_stem_compact(const int32_t* flags, int64_t B, int64_t H, int64_t W, int32_t* scan, void* scan_ws, int64_t scan_ws_bytes,
-                      int32_t* row_cell, int32_t* row_of, int32_t* meta, smos_stream_t stream);
-/* rows[0 .. meta[11]) <- 0 (row_floats floats per row): the zero fill of the compact row table of
- * smos_pointnet_scatter_rows, sized on the device. */
-int smos_stem_zero_rows(float* rows, const int32_t* meta, int64_t row_floats, smos_stream_t stream);
+                   uint64_t* scan_state, smos_stream_t stream);
+int smos_stem_scan(int32_t* flags, int64_t B, int64_t H, int64_t W, uint64_t* scan_state, int32_t* row_cell, int32_t* row_of,
+                   int32_t* meta, float* rows, int64_t row_floats, smos_stream_t stream);
 int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4, float* const* y4,
                    int64_t Cin, int64_t Cout, smos_stream_t stream);
 int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias, float* out,
@@ -278,8 +278,8 @@ int64_t smos_point_head_weight_floats(void);
 int smos_point_head(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N, int64_t K1,
                     int64_t M1, int64_t M2, int64_t M3, smos_stream_t stream);
 
-/* smos_pointnet_scatter with a COMPACT target: rows [n_rows, T*cout] (zero-filled by smos_stem_zero_rows) instead of
- * the dense [B,H,W,T*cout] grid; the features of cell (b, y, x) go to row row_of[b][y][x] (smos_stem_compact). */
+/* smos_pointnet_scatter with a COMPACT target: rows [n_rows, T*cout] (zero-filled by smos_stem_scan) instead of
+ * the dense [B,H,W,T*cout] grid; the features of cell (b, y, x) go to row row_of[b][y][x] (smos_stem_scan). */
 int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
                                const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
                                int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,

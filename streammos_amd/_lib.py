@@ -35,13 +35,12 @@ SIGNATURES = {
     "smos_downsample_epilogue": [vp, c_i64p, vp, c_i64p, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
     "smos_channel_gate_residual": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, vp],
     "smos_pointnet_scatter": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
-    "smos_stem_mark": [vp, i32, i64, i64, i64, i64, i64, vp, vp],
-    "smos_stem_scan_bytes": [i64],
-    "smos_stem_compact": [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp],
+    "smos_stem_scan_state_words": [i64],
+    "smos_stem_mark": [vp, i32, i64, i64, i64, i64, i64, vp, vp, vp],
+    "smos_stem_scan": [vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, vp],
     "smos_stem_gemm": [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), i64, i64, vp],
     "smos_stem_epilogue": [ctypes.POINTER(vp), vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_pointnet_scatter_rows": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
-    "smos_stem_zero_rows": [vp, vp, i64, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -87,7 +86,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
-    lib.smos_stem_scan_bytes.restype = ctypes.c_int64
+    lib.smos_stem_scan_state_words.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p

@@ -6,7 +6,7 @@
 // is occupied: a max-pool scatter leaves every cell no LiDAR point fell into at exactly 0, and both convolutions are
 // linear, so empty cells contribute nothing.  The engine therefore
 //   1. marks the occupied cells from the point coordinates (stem_mark, this file),
-//   2. compacts them with one prefix sum (stem_compact; rows ordered by the PARITY CLASS of the cell: with stride 2 a
+//   2. compacts them with one single-pass prefix sum (stem_scan; rows ordered by the PARITY CLASS of the cell: with stride 2 a
 //      cell at odd y feeds kernel rows ky in {0, 2}, a cell at even y only ky = 1, same for x -- 4, 2, 2 or 1 of the 9
 //      taps, 2.25 on average),
 //   3. multiplies the occupied rows [n_c, 192], read in place from the grid, with the class's tap weights
@@ -15,7 +15,6 @@
 //   4. and assembles the output per pixel in a fixed tap order (stem_epilogue): deterministic, no atomics.
 // 5 x fewer FLOPs than the dense convolutions and the 805 MB grid is read only where it is occupied.
 #include "smos_common.h"
-#include <hipcub/hipcub.hpp>
 
 namespace smos {
 
@@ -26,10 +25,21 @@ __device__ __forceinline__ int64_t perm_index(int b, int y, int x, int B, int H,
   return (((int64_t)cls * B + b) * hh + (y >> 1)) * wh + (x >> 1);
 }
 
+// Single-pass scan state (decoupled look-back): tile descriptors = one 64-bit word {status, value} each, written and read
+// with ONE agent-scope 8-byte atomic (the value travels inside the flag word, so no fence is needed), plus the ticket
+// counter that hands out tile ids in execution order (a tile only ever waits for tiles that have already started).
+constexpr int kScanItems = 8, kScanTile = kBlock * kScanItems, kScanMaxTiles = 1 << 16;
+constexpr unsigned long long kScanAggregate = 1ULL << 32, kScanInclusive = 2ULL << 32;
+
 // flags[perm_index(b, y, x)] = 1 for every cell a point of any of the T frames falls into (same cell rule as the
-// scatter, point_deep_cuda_kernel.cu:39-47: valid when -1 < coord < size, cell = trunc(coord))
+// scatter, point_deep_cuda_kernel.cu:39-47: valid when -1 < coord < size, cell = trunc(coord)).  flags must be all zero
+// on entry; stem_scan, which consumes them, leaves them all zero again.  Block 0 also re-arms the scan state of the
+// stem_scan launch that follows on the stream (no memset launch, nothing frozen into a captured graph).
 __global__ __launch_bounds__(kBlock) void stem_mark(const float* __restrict__ coord, int K, int B, int T, int64_t N, int H, int W,
-                                                    int32_t* __restrict__ flags) {
+                                                    int32_t* __restrict__ flags, unsigned long long* __restrict__ scan_state,
+                                                    int n_tiles) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i <= n_tiles; i += kBlock) scan_state[i] = 0;      // [0] = ticket counter, [1 + t] = tile t
   const int64_t total = (int64_t)B * T * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const float py = coord[i * K], px = coord[i * K + 1];
@@ -40,37 +50,93 @@ __global__ __launch_bounds__(kBlock) void stem_mark(const float* __restrict__ co
   }
 }
 
-// scan = exclusive prefix sum of flags (permuted order).  row_cell[row] = natural cell id (b*H + y)*W + x of the row;
-// row_of[natural cell] = row or -1; meta[0..3] = rows per class, meta[4..7] = first row of each class.
-__global__ __launch_bounds__(kBlock) void stem_rows(const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int B, int H,
-                                                    int W, int32_t* __restrict__ row_cell, int32_t* __restrict__ row_of,
-                                                    int32_t* __restrict__ meta) {
+// One pass over the flags (permuted order = row order): exclusive prefix sum by decoupled look-back, then per cell
+// row_of[natural cell] = row or -1, row_cell[row] = natural cell id (b*H + y)*W + x, the flags cleared for the next frame,
+// the class boundaries in meta (meta[4 + c] = first row of class c, meta[8 + c] = one past its last row, so meta[11] = the
+// number of rows), and the zero fill of exactly the rows this tile creates in the compact table (rows, row_f4 float4 per
+// row; may be null).  Replaces a 3-kernel library scan + 3 bookkeeping kernels + the zero-fill launch.
+__global__ __launch_bounds__(kBlock) void stem_scan(int32_t* __restrict__ flags, int B, int H, int W,
+                                                    unsigned long long* __restrict__ scan_state, int32_t* __restrict__ row_cell,
+                                                    int32_t* __restrict__ row_of, int32_t* __restrict__ meta,
+                                                    float4* __restrict__ rows, int row_f4) {
+  __shared__ int s_tile, s_wave[kBlock / 64], s_prefix;
   const int hh = H >> 1, wh = W >> 1;
   const int64_t per = (int64_t)B * hh * wh, total = 4 * per;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cls = (int)(i / per);
-    int64_t r = i - (int64_t)cls * per;
-    const int b = (int)(r / ((int64_t)hh * wh));
-    r -= (int64_t)b * hh * wh;
-    const int y = (int)(r / wh) * 2 + (cls >> 1), x = (int)(r % wh) * 2 + (cls & 1);
-    const int32_t cell = (b * H + y) * W + x;
-    const int32_t f = flags[i], at = scan[i];
-    row_of[cell] = f ? at : -1;
-    if (f) row_cell[at] = cell;
-    if (r == 0 && b == 0) meta[4 + cls] = at;                              // first entry of the class
-    if (i == (int64_t)(cls + 1) * per - 1) meta[8 + cls] = at + f;          // one past the class's last row
+  if (threadIdx.x == 0) s_tile = (int)atomicAdd(scan_state, 1ULL);
+  __syncthreads();
+  const int tile = s_tile;
+  const int64_t i0 = (int64_t)tile * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  // this thread's kScanItems consecutive flags (total is a multiple of 4; tiles may end ragged)
+  int f[kScanItems], count = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k += 4) {
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i0 + k < total) {
+      v = *reinterpret_cast<const int4*>(flags + i0 + k);
+      *reinterpret_cast<int4*>(flags + i0 + k) = make_int4(0, 0, 0, 0);
+    }
+    f[k] = v.x; f[k + 1] = v.y; f[k + 2] = v.z; f[k + 3] = v.w;
+    count += v.x + v.y + v.z + v.w;
   }
-}
-
-__global__ void stem_meta(int32_t* meta) {
-  if (threadIdx.x < 4) meta[threadIdx.x] = meta[8 + threadIdx.x] - meta[4 + threadIdx.x];
-}
-
-// zero-fill of the compact row table: only the rows that exist (their number is on the device)
-__global__ __launch_bounds__(kBlock) void stem_zero_rows(float4* __restrict__ rows, const int32_t* __restrict__ meta, int row_f4) {
-  const int64_t total = (int64_t)meta[11] * row_f4;    // meta[8 + 3] = one past the last row of the last class
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // block-wide exclusive scan of the per-thread counts: wave shuffles, then the four wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = count;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int wave_off = 0, aggregate = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) wave_off += s_wave[w];
+    aggregate += s_wave[w];
+  }
+  // decoupled look-back (one lane): publish the aggregate, walk back until a tile that knows its inclusive prefix
+  if (threadIdx.x == 0) {
+    unsigned long long* desc = scan_state + 1;
+    int prefix = 0;
+    if (tile > 0) {
+      __hip_atomic_store(desc + tile, kScanAggregate | (unsigned)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int t = tile - 1;; --t) {
+        unsigned long long d;
+        while (((d = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0)
+          __builtin_amdgcn_s_sleep(1);
+        prefix += (int)(unsigned)d;
+        if ((d >> 32) == 2) break;
+      }
+    }
+    __hip_atomic_store(desc + tile, kScanInclusive | (unsigned)(prefix + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_prefix = prefix;
+  }
+  __syncthreads();
+  const int tile_first = s_prefix;
+  int at = tile_first + wave_off + incl - count;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = i0 + k;
+    if (i < total) {
+      const int cls = (int)(i / per);
+      int64_t r = i - (int64_t)cls * per;
+      const int b = (int)(r / ((int64_t)hh * wh));
+      r -= (int64_t)b * hh * wh;
+      const int y = (int)(r / wh) * 2 + (cls >> 1), x = (int)(r % wh) * 2 + (cls & 1);
+      const int32_t cell = (b * H + y) * W + x;
+      row_of[cell] = f[k] ? at : -1;
+      if (f[k]) row_cell[at] = cell;
+      if (i == (int64_t)cls * per) meta[4 + cls] = at;                           // first cell of the class
+      if (i == (int64_t)(cls + 1) * per - 1) meta[8 + cls] = at + f[k];          // its last cell
+      at += f[k];
+    }
+  }
+  // zero fill of the rows this tile created: [tile_first, tile_first + aggregate)
+  if (rows) {
+    float4* dst = rows + (int64_t)tile_first * row_f4;
+    const int64_t n = (int64_t)aggregate * row_f4;
+    for (int64_t j = threadIdx.x; j < n; j += kBlock) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // Y_cls[r][mt*32 + c] = sum_k W_cls[mt*32 + c][k] * X[row_cell[start + r]][k]   (k = 0..191) on the matrix cores, in the
@@ -87,7 +153,7 @@ __device__ __forceinline__ void stem_gemm_class(const float* __restrict__ bev, c
                                                 float* __restrict__ y, float* lds_w, int block, int n_blocks) {
   for (int i = threadIdx.x; i < kM * kStemSteps * 64; i += kStemBlock) lds_w[i] = wprep[i];   // [kM][96][64]
   __syncthreads();
-  const int n = meta[cls], start = meta[4 + cls];
+  const int start = meta[4 + cls], n = meta[8 + cls] - start;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, hh = lane >> 5;
   constexpr int kWaves = kStemBlock / 64;
@@ -221,42 +287,36 @@ __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
 
 using namespace smos;
 
+extern "C" int64_t smos_stem_scan_state_words(int64_t cells) {
+  if (cells <= 0 || cells >= (1LL << 31)) return -1;
+  const int64_t tiles = (cells + kScanTile - 1) / kScanTile;
+  return tiles <= kScanMaxTiles ? 1 + tiles : -1;
+}
+
 extern "C" int smos_stem_mark(const float* coord, int32_t K, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t* flags,
-                              smos_stream_t stream) {
+                              uint64_t* scan_state, smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && T > 0 && N >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && K >= 2 && B * H * W < (1LL << 31),
                "stem_mark: bad sizes (H and W must be even)");
-  if (N == 0) return SMOS_OK;
-  SMOS_REQUIRE(coord && flags, "stem_mark: null device pointer");
-  hipLaunchKernelGGL(stem_mark, dim3(grid_for(B * T * N)), dim3(kBlock), 0, (hipStream_t)stream, coord, (int)K, (int)B, (int)T, N,
-                     (int)H, (int)W, flags);
+  SMOS_REQUIRE(flags && scan_state && (N == 0 || coord) && smos_stem_scan_state_words(B * H * W) > 0, "stem_mark: null device pointer / grid too large");
+  const int n_tiles = (int)(smos_stem_scan_state_words(B * H * W) - 1);
+  hipLaunchKernelGGL(stem_mark, dim3(grid_for(B * T * N > 0 ? B * T * N : 1)), dim3(kBlock), 0, (hipStream_t)stream, coord, (int)K, (int)B,
+                     (int)T, N, (int)H, (int)W, flags, reinterpret_cast<unsigned long long*>(scan_state), n_tiles);
   return check_launch("stem_mark");
 }
 
-extern "C" int64_t smos_stem_scan_bytes(int64_t cells) {
-  if (cells <= 0 || cells >= (1LL << 31)) return -1;
-  size_t bytes = 0;
-  if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cells) != hipSuccess) return -1;
-  return (int64_t)bytes;
-}
-
-extern "C" int smos_stem_compact(const int32_t* flags, int64_t B, int64_t H, int64_t W, int32_t* scan, void* scan_ws,
-                                 int64_t scan_ws_bytes, int32_t* row_cell, int32_t* row_of, int32_t* meta, smos_stream_t stream) {
-  SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && B * H * W < (1LL << 31), "stem_compact: bad sizes");
-  SMOS_REQUIRE(flags && scan && scan_ws && row_cell && row_of && meta, "stem_compact: null device pointer");
-  const int64_t cells = B * H * W;
-  size_t need = 0;
-  SMOS_REQUIRE(hipcub::DeviceScan::ExclusiveSum(nullptr, need, flags, scan, (int)cells) == hipSuccess && (int64_t)need <= scan_ws_bytes,
-               "stem_compact: scan workspace too small");
-  hipStream_t s = (hipStream_t)stream;
-  size_t bytes = (size_t)scan_ws_bytes;
-  if (hipcub::DeviceScan::ExclusiveSum(scan_ws, bytes, flags, scan, (int)cells, s) != hipSuccess) {
-    set_error("stem_compact: prefix sum failed");
-    return SMOS_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(stem_rows, dim3(grid_for(cells)), dim3(kBlock), 0, s, flags, (const int32_t*)scan, (int)B, (int)H, (int)W, row_cell,
-                     row_of, meta);
-  hipLaunchKernelGGL(stem_meta, dim3(1), dim3(64), 0, s, meta);
-  return check_launch("stem_compact");
+extern "C" int smos_stem_scan(int32_t* flags, int64_t B, int64_t H, int64_t W, uint64_t* scan_state, int32_t* row_cell,
+                              int32_t* row_of, int32_t* meta, float* rows, int64_t row_floats, smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && smos_stem_scan_state_words(B * H * W) > 0, "stem_scan: bad sizes");
+  SMOS_REQUIRE(flags && scan_state && row_cell && row_of && meta && (reinterpret_cast<uintptr_t>(flags) & 15) == 0,
+               "stem_scan: null / unaligned device pointer");
+  SMOS_REQUIRE(!rows || (row_floats > 0 && row_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0),
+               "stem_scan: bad row table");
+  const int n_tiles = (int)(smos_stem_scan_state_words(B * H * W) - 1);
+  // every tile waits only for tiles with a smaller ticket, i.e. for blocks that are already running
+  hipLaunchKernelGGL(stem_scan, dim3(n_tiles), dim3(kBlock), 0, (hipStream_t)stream, flags, (int)B, (int)H, (int)W,
+                     reinterpret_cast<unsigned long long*>(scan_state), row_cell, row_of, meta, reinterpret_cast<float4*>(rows),
+                     (int)(row_floats / 4));
+  return check_launch("stem_scan");
 }
 
 extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const int32_t* meta, const float* const* wprep4,
@@ -286,14 +346,6 @@ extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const i
   a.first_block[4] = at;
   hipLaunchKernelGGL(stem_gemm, dim3(at), dim3(kStemBlock), lds, (hipStream_t)stream, a);
   return check_launch("stem_gemm");
-}
-
-extern "C" int smos_stem_zero_rows(float* rows, const int32_t* meta, int64_t row_floats, smos_stream_t stream) {
-  SMOS_REQUIRE(rows && meta && row_floats > 0 && row_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0,
-               "stem_zero_rows: bad arguments");
-  hipLaunchKernelGGL(stem_zero_rows, dim3(256 * 8), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<float4*>(rows), meta,
-                     (int)(row_floats / 4));
-  return check_launch("stem_zero_rows");
 }
 
 extern "C" int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias,

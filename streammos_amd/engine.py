@@ -433,7 +433,7 @@ class InferenceEngine:
         if self.sparse_stem and self.stem_w is not None:
             # sparse first stage: the occupancy of the grid follows from the coordinates alone, so the point MLP scatters
             # into a compact row table (one row per occupied cell) and the 805 MB dense grid is never built
-            plan = ops.stem_plan(pcds_coord, hb, wb)
+            plan = ops.stem_plan(pcds_coord, hb, wb, row_floats=t * cpt)
             rows = ops.pointnet_scatter_rows(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1],
                                              plan, pts_out=fuse[:, :, :o1])
             x = ops.sparse_downsample(rows, plan, self.stem_w, self.header_bev[0].bias, compact=True)

@@ -556,18 +556,19 @@ def stem_prepare_weights(wa, wp):
 _stem_ws = {}
 
 
-def _stream_workspace(tag, shape, dtype, device):
+def _stream_workspace(tag, shape, dtype, device, zero=False):
     """Scratch of the sparse first stage, one flat buffer per (device, HIP stream, tag), grown to the largest request
     seen: consecutive frames on a stream reuse it in stream order instead of holding a fresh allocation per frame that
     the host has enqueued ahead of the GPU.  The returned view is valid until the next request with the same tag on the
-    same stream (callers consume it within the frame).  ``release_stream_workspaces`` frees them."""
+    same stream (callers consume it within the frame).  zero=True: zero-filled when (re)allocated -- for buffers whose
+    users leave them zero (the occupancy flags).  ``release_stream_workspaces`` frees them."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, dtype)
     need = 1
     for d in shape:
         need *= int(d)
     buf = _stem_ws.get(key)
     if buf is None or buf.numel() < need:
-        buf = _stem_ws[key] = torch.empty(need, dtype=dtype, device=device)
+        buf = _stem_ws[key] = (torch.zeros if zero else torch.empty)(need, dtype=dtype, device=device)
     return buf[:need].view(shape)
 
 
@@ -579,16 +580,23 @@ def release_stream_workspaces(device=None, stream=None):
 
 
 class StemPlan:
-    """Occupancy of the input grid of one frame (csrc/stem.hip): which cells hold points, in which compact row."""
+    """Occupancy of the input grid of one frame (csrc/stem.hip): which cells hold points, in which compact row.
+    meta (device, 12 x int32): [4..7] first row of each parity class, [8..11] one past its last row; meta[11] = rows."""
 
-    def __init__(self, b, h, w, flags, row_cell, row_of, meta):
+    def __init__(self, b, h, w, row_cell, row_of, meta, rows):
         self.b, self.h, self.w = b, h, w
-        self.flags, self.row_cell, self.row_of, self.meta = flags, row_cell, row_of, meta
+        self.row_cell, self.row_of, self.meta, self.rows = row_cell, row_of, meta, rows
+
+    def class_rows(self):
+        """device tensor [4]: occupied cells per parity class (y & 1) * 2 + (x & 1)"""
+        return self.meta[8:12] - self.meta[4:8]
 
 
-def stem_plan(coord, h, w):
+def stem_plan(coord, h, w, row_floats=0):
     """coord [B,T,N,K(,1)] float32 contiguous -> StemPlan: marks the cells the points fall into and compacts them (rows
-    ordered by parity class, sample, position).  Everything stays on the device."""
+    ordered by parity class, sample, position) in two launches (mark, single-pass scan).  row_floats > 0 also provides the
+    compact row table ``plan.rows`` [min(B*H*W, B*T*N), row_floats] with its existing rows zero-filled (by the scan kernel).
+    Everything stays on the device; every buffer is per-stream scratch, valid until the next plan on the stream."""
     _require_cuda("stem_plan", coord)
     if coord.dtype != torch.float32 or not coord.is_contiguous():
         raise RuntimeError("stem_plan: coord must be contiguous float32")
@@ -596,45 +604,47 @@ def stem_plan(coord, h, w):
     dev = coord.device
     cells = b * h * w
     lib = _lib.load()
-    scan_bytes = int(lib.smos_stem_scan_bytes(cells))
-    if scan_bytes < 0:
-        raise RuntimeError("stem_plan: scan workspace query failed")
-    flags = torch.zeros(cells, dtype=torch.int32, device=dev)
-    scan = torch.empty(cells, dtype=torch.int32, device=dev)
-    scan_ws = torch.empty(max(scan_bytes, 1), dtype=torch.uint8, device=dev)
-    row_cell = torch.empty(cells, dtype=torch.int32, device=dev)
-    row_of = torch.empty(cells, dtype=torch.int32, device=dev)
-    meta = torch.zeros(12, dtype=torch.int32, device=dev)
+    words = int(lib.smos_stem_scan_state_words(cells))
+    if words < 0:
+        raise RuntimeError("stem_plan: grid too large for the scan")
+    flags = _stream_workspace("stem_flags", (cells,), torch.int32, dev, zero=True)      # left all-zero by the scan
+    state = _stream_workspace("stem_scan_state", (words,), torch.int64, dev)
+    row_cell = _stream_workspace("stem_row_cell", (cells,), torch.int32, dev)
+    row_of = _stream_workspace("stem_row_of", (cells,), torch.int32, dev)
+    meta = _stream_workspace("stem_meta", (12,), torch.int32, dev, zero=True)
+    rows = None
+    if row_floats:
+        # capacity: an occupied cell holds at least one point, so min(cells, points) rows always suffice
+        rows = _stream_workspace("stem_rows", (min(cells, b * t * n), row_floats), torch.float32, dev)
     st = _stream(coord)
-    with torch.cuda.device(dev), profiling.span("stem_mark+compact[%dx%dx%d]" % (b, h, w)):
-        _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), st), "smos_stem_mark")
-        _lib.check(lib.smos_stem_compact(flags.data_ptr(), b, h, w, scan.data_ptr(), scan_ws.data_ptr(), scan_ws.numel(),
-                                         row_cell.data_ptr(), row_of.data_ptr(), meta.data_ptr(), st), "smos_stem_compact")
-    return StemPlan(b, h, w, flags, row_cell, row_of, meta)
+    with torch.cuda.device(dev), profiling.span("stem_mark+scan[%dx%dx%d]" % (b, h, w)):
+        _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), state.data_ptr(), st), "smos_stem_mark")
+        _lib.check(lib.smos_stem_scan(flags.data_ptr(), b, h, w, state.data_ptr(), row_cell.data_ptr(), row_of.data_ptr(),
+                                      meta.data_ptr(), rows.data_ptr() if rows is not None else None, row_floats, st), "smos_stem_scan")
+    return StemPlan(b, h, w, row_cell, row_of, meta, rows)
 
 
 def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
-    """pointnet_scatter into the COMPACT row table of `plan`: returns rows [min(B*H*W, B*T*N) (capacity), T*64], a view
-    of this stream's scratch (valid until the next call on the stream); only the first plan.meta[11] rows exist (zero-filled here, on the device-side count) -- the dense grid is never materialised."""
+    """pointnet_scatter into the COMPACT row table of `plan` (stem_plan(..., row_floats=T*64)): returns plan.rows, a view of
+    this stream's scratch (valid until the next plan on the stream); only the first plan.meta[11] rows exist (zero-filled by
+    the plan's scan) -- the dense grid is never materialised."""
     _require_cuda("pointnet_scatter_rows", xyzi, coord, w1, b1, w2, b2, pts_out)
     b, t, cin, n = xyzi.shape[:4]
     k = coord.shape[3]
     if not (xyzi.is_contiguous() and coord.is_contiguous()):
         raise RuntimeError("pointnet_scatter_rows: xyzi and coord must be contiguous")
     cout = w2.shape[0]
-    # capacity: an occupied cell holds at least one point, so min(cells, points) rows always suffice
-    rows = _stream_workspace("stem_rows", (min(plan.b * plan.h * plan.w, b * t * n), t * cout), torch.float32, xyzi.device)
+    rows = plan.rows
+    if rows is None or rows.shape[1] != t * cout:
+        raise RuntimeError("pointnet_scatter_rows: the plan carries no row table of %d floats per row" % (t * cout))
     po_b = po_n = 0
     if pts_out is not None:
         po_b, po_n = _rows("pointnet_scatter_rows", pts_out, cout)
     lib = _lib.load()
     st = _stream(xyzi)
-    with torch.cuda.device(xyzi.device):
-        with profiling.span("stem_zero_rows[%dx%dx%dx%d]" % (b, plan.h, plan.w, t * cout)):
-            _lib.check(lib.smos_stem_zero_rows(rows.data_ptr(), plan.meta.data_ptr(), t * cout, st), "smos_stem_zero_rows")
-        # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
-        with profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
-            rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+    # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
+    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
+        rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                             b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
                                             pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
                                             plan.h, plan.w, cin, w1.shape[0], cout, st)

@@ -160,12 +160,20 @@ def test_sparse_stem_equals_dense_downsample(model, fill):
     assert (got - want).abs().max().item() <= 1e-5 * scale
     assert ((got > 0) == (want > 0)).float().mean().item() > 0.9999
     # the engine's own route: the point MLP scatters into compact rows, the dense grid is never built
-    plan = ops.stem_plan(coord, h, w)
+    plan = ops.stem_plan(coord, h, w, row_floats=t * 64)
+    assert not bool(ops._stream_workspace("stem_flags", (b * h * w,), torch.int32, coord.device).any())    # scan cleared the flags
     rows = ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)
     n_rows = int(plan.meta[11])
     row_of = plan.row_of.long()
     occupied = row_of >= 0
-    assert int(occupied.sum()) == n_rows == int(plan.meta[:4].sum())
+    assert int(occupied.sum()) == n_rows == int(plan.class_rows().sum()) and int(plan.meta[4]) == 0
+    # rows are numbered in parity-class-major order, each exactly once
+    assert torch.equal(torch.sort(row_of[occupied])[0], torch.arange(n_rows, device=DEV))
+    cells = plan.row_cell[:n_rows].long()
+    assert torch.equal(row_of[cells], torch.arange(n_rows, device=DEV))
+    cy, cx = (cells // w) % h, cells % w
+    cls = ((cy & 1) * 2 + (cx & 1))
+    assert bool((cls[1:] >= cls[:-1]).all())
     dense_rows = bev_cl.view(b * h * w, -1)
     assert torch.equal(rows[row_of[occupied]], dense_rows[occupied])          # same maxima, bit for bit
     assert not bool(dense_rows[~occupied].any())                              # and nothing outside the marked cells

@@ -29,8 +29,8 @@ with torch.no_grad(), eng._conv_flags():
     print("sparse (total)  %.3f ms" % timeit(lambda: eng._stem_sparse_cl(bev_cl, coord)))
     t = lambda fn: timeit(fn)
     print("dense scatter (fill + kernel)   %.3f ms" % t(lambda: ops.pointnet_scatter(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], bev_cl, zero_fill=True)))
-    print("plan (mark + compact)           %.3f ms" % t(lambda: ops.stem_plan(coord, 512, 512)))
-    plan = ops.stem_plan(coord, 512, 512)
+    print("plan (mark + scan incl. zero fill) %.3f ms" % t(lambda: ops.stem_plan(coord, 512, 512, row_floats=192)))
+    plan = ops.stem_plan(coord, 512, 512, row_floats=192)
     print("compact scatter (fill + kernel) %.3f ms" % t(lambda: ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)))
     rows = ops.pointnet_scatter_rows(xyzi, coord, eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1], plan)
     print("sparse downsample, dense src    %.3f ms" % t(lambda: ops.sparse_downsample(bev_cl, plan, eng.stem_w, eng.header_bev[0].bias, compact=False)))
