@@ -237,10 +237,14 @@ def vote_frame(cur_points, cur_pred, hist_points, hist_pred):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Instance-level voting (voxel_instance_voting.py:144-193, 195-272).  PARITY UNPINNED against the reference itself: the
-# script cannot be imported (np.bool, scipy.spatial.qhull, yaml.load without Loader, argparse at module level), so
-# this restatement follows its source text and calls the same third-party routines (scikit-learn DBSCAN, scipy
-# ConvexHull / Delaunay, unpinned in requirements.txt:3,9) that the reference calls.
+# Instance-level voting (voxel_instance_voting.py:144-193, 195-272).  PINNED: the script cannot be imported (argparse,
+# yaml.load without Loader, a dataset walk and a process pool at module level), but its functions -- post_processing()
+# included -- are extracted from the source text and run on a synthetic sequence by tests/golden/make_golden.py; the label
+# files they write are tests/golden/instance.npz, and tests/test_oracle_golden.py::test_instance_voting_matches_reference
+# holds this restatement to them bit for bit.  It calls the same third-party routines as the reference (scikit-learn
+# DBSCAN, scipy ConvexHull / Delaunay; unpinned in requirements.txt:3,9 -- here scikit-learn 1.7, scipy 1.15).  Not
+# covered by the fixture: a degenerate (coplanar) cluster, where the reference's except branch itself fails on current
+# numpy / scipy (np.bool, scipy.spatial.qhull).
 # ---------------------------------------------------------------------------------------------------
 def instance_box_corners(cluster_points):
     """min_bounding_box_3d (:43-60): the axis-aligned box of the convex-hull vertices, i.e. of the points.  The
@@ -304,3 +308,14 @@ def instance_vote_frame(cur_points, cur_pred, cur_bf, hist_points, hist_pred):
     local_pred = np.concatenate((np.asarray(hist_pred)[hk], np.asarray(cur_pred)[ck]), axis=0).astype(np.int64)
     voted = vote_frame(cur_points, cur_pred, hist_points, hist_pred)
     return instance_cluster(cur_points, voted, cur_bf, local_points, local_pred)
+
+
+def instance_cluster_stats(cur_points, cur_pred, cur_bf, eps=0.3, min_samples=5):
+    """DBSCAN clusters of the foreground of one frame: [{points}] (used by the fixture generator to assert which cases a
+    synthetic frame exercises)."""
+    from sklearn.cluster import DBSCAN
+    fg = np.where(np.asarray(cur_bf) == 2)[0]
+    if len(fg) == 0:
+        return []
+    lab = DBSCAN(eps=eps, min_samples=min_samples).fit_predict(np.asarray(cur_points)[fg][:, :3])
+    return [{"points": int((lab == c).sum())} for c in np.unique(lab) if c != -1]

@@ -99,3 +99,26 @@ def _extract_voting_functions():
     mod.__dict__.update(np=np, torch=torch)
     exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), mod.__dict__)
     return mod
+
+
+def extract_instance_voting(namespace_overrides):
+    """voxel_instance_voting.py also runs at import (argparse, yaml.load, a dataset walk and a process pool at module
+    level, :272-352), so its functions (:17-270: map, min_bounding_box_3d, in_hull, get_point_labels_from_voxel_labels,
+    determine_voxel_labels, Quantize, get_data, cluster, post_processing) are pulled out of the source text and executed in
+    a module whose globals the caller provides (what the script's module level would have defined: files, poses_list,
+    data_path, pred_path, pred_bf_path, save_path, task_cfg, crop_to_fov, frames_num_max, utils).  Only the degenerate-hull
+    `except` branch of in_hull touches names that no longer exist (np.bool, scipy.spatial.qhull); nothing else is altered."""
+    import copy
+    import numpy as np
+    import scipy
+    import torch
+    from scipy.spatial import ConvexHull, Delaunay
+    from sklearn.cluster import DBSCAN
+    path = os.path.join(REF_ROOT, "voxel_instance_voting.py")
+    tree = ast.parse(open(path).read(), path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef)]
+    mod = types.ModuleType("smos_ref_voxel_instance_voting_functions")
+    mod.__dict__.update(np=np, torch=torch, scipy=scipy, copy=copy, os=os, DBSCAN=DBSCAN, ConvexHull=ConvexHull, Delaunay=Delaunay)
+    mod.__dict__.update(namespace_overrides)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), mod.__dict__)
+    return mod

@@ -164,3 +164,49 @@ def e2e_frames(n_frames=3, tta_rows=(0, 3)):
         s = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], E2E_POINTS, spec, tta=True)
         rows = list(tta_rows)
         yield {k: np.ascontiguousarray(s[k][rows]) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+
+
+def instance_sequence(n_frames=10):
+    """Synthetic sequence for the instance-voting fixture (voxel_instance_voting.py:195-272): per frame a raw scan (n,4)
+    float32, the network's per-point prediction in {0,1,2}, the movable-object (`_bf`) prediction (2 = foreground) and a
+    4x4 pose.  Foreground objects are 1 m tall columns that travel with the sensor (so a box mostly holds the current
+    frame's own points): A (60 points), B (exactly 30: NOT processed, the reference wants > 30), C (exactly 31), D and E
+    with hand-set predictions inside their lifted boxes (D: four 1s and two 2s -- the reference compares SUMS of labels,
+    4 vs 4, a tie -> static; E: three 1s and two 2s, 3 vs 4 -> moving although 2s are the minority), F far outside the
+    voting crop, a sparse 4-point group (DBSCAN noise).  Every cluster's extreme points lie exactly on its box faces."""
+    frames = []
+    for k in range(n_frames):
+        r = _rng(9000 + k)
+        parts, preds, bfs = [], [], []
+
+        def add(xyz, pred, bf):
+            parts.append(np.asarray(xyz, dtype=np.float32))
+            preds.append(np.asarray(pred, dtype=np.uint8))
+            bfs.append(np.full(len(xyz), bf, dtype=np.uint8))
+
+        g = np.stack((r.uniform(-30, 30, 500), r.uniform(-30, 30, 500), r.normal(-1.75, 0.01, 500)), -1)
+        add(g, np.where(r.random(500) < 0.03, 2, 1), 1)                                     # ground, a few false movers
+
+        def column(cx, cy, n, z0=-1.5, z1=-0.5):
+            return np.stack((r.normal(cx, 0.04, n), r.normal(cy, 0.04, n), np.sort(r.uniform(z0, z1, n))), -1)
+
+        add(column(8.0, 3.0, 60), np.where(r.random(60) < 0.8, 2, 1), 2)                      # A: mostly moving
+        add(column(-6.0, 5.0, 30), np.full(30, 2), 2)                                        # B: 30 points
+        add(column(-6.0, -7.0, 31), np.where(r.random(31) < 0.3, 2, 1), 2)                   # C: 31 points
+        for (cx, cy, ones, twos) in ((12.0, -9.0, 4, 2), (15.0, 9.0, 3, 2)):               # D (tie), E (minority wins)
+            col = column(cx, cy, 40)
+            # points are sorted by z: the box floor is lifted by 0.2, so give labels by height -- everything below
+            # z_min + 0.25 is 0 (not counted wherever the face falls), the next `ones` points 1, then `twos` points 2, rest 0
+            pr = np.zeros(40, dtype=np.uint8)
+            above = np.nonzero(col[:, 2] > col[0, 2] + 0.25)[0]
+            pr[above[:ones]] = 1
+            pr[above[ones:ones + twos]] = 2
+            add(col, pr, 2)
+        add(column(70.0, 0.0, 45), np.full(45, 2), 2)                                        # F: outside the +-50 m crop
+        add(np.stack((r.uniform(20, 24, 4), r.uniform(-20, -16, 4), r.uniform(-1, 0, 4)), -1), np.full(4, 2), 2)   # noise
+        xyz = np.concatenate(parts, 0)
+        scan = np.concatenate((xyz, r.random((len(xyz), 1)).astype(np.float32)), 1).astype(np.float32)
+        perm = r.permutation(len(scan))                                                    # file order is not object order
+        frames.append((np.ascontiguousarray(scan[perm]), np.concatenate(preds)[perm], np.concatenate(bfs)[perm],
+                       synth.synthetic_pose(k)))
+    return frames

@@ -199,13 +199,62 @@ def gen_losses(ns, out):
     out["grad"] = torch.autograd.grad(a + 3 * b, pred)[0].numpy()
 
 
+def gen_instance(ns, out):
+    """Row f3: the reference's own post_processing() (voxel_instance_voting.py:195-270: voxel vote, then cluster() = DBSCAN +
+    hull box + in-box majority) run on a synthetic sequence written to a temporary SemanticKITTI-style tree; the fixture
+    holds the refined label words it writes for every frame.  The script's module level is replaced by the globals it
+    would have defined; `.cuda()` is the identity here (no GPU in the build container)."""
+    import tempfile
+    import yaml
+    spec = importlib.util.spec_from_file_location(
+        "smos_ref_dataset_utils", os.path.join(ref_import.REF_ROOT, "datasets", "utils.py"))
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    task_cfg = yaml.safe_load(open(os.path.join(ref_import.REF_ROOT, "datasets", "semantic-kitti.yaml")))
+    frames = cases.instance_sequence()
+    lut = np.zeros(256, dtype=np.uint32)
+    lut[1], lut[2] = 9, 251
+    with tempfile.TemporaryDirectory() as tmp:
+        dirs = {k: os.path.join(tmp, k) + "/" for k in ("velodyne", "pred", "pred_bf", "refined")}
+        for d in dirs.values():
+            os.makedirs(d)
+        files = []
+        for k, (scan, pred, bf, pose) in enumerate(frames):
+            name = "%06d.bin" % k
+            files.append(name)
+            scan.tofile(dirs["velodyne"] + name)
+            lut[pred].tofile(dirs["pred"] + name[:-4] + ".label")                      # val_StreamMOS_seg.py:139-140: LUT words
+            bf.astype(np.uint32).tofile(dirs["pred_bf"] + name[:-4] + ".label")         # :141: raw 0 / 1 / 2
+        mod = ref_import.extract_instance_voting(dict(
+            utils=du, task_cfg=task_cfg, files=files, poses_list=[f[3] for f in frames], frames_num_max=8,
+            data_path=dirs["velodyne"], pred_path=dirs["pred"], pred_bf_path=dirs["pred_bf"], save_path=dirs["refined"],
+            crop_to_fov=ns.transforms.Crop(dims=(0, 1, 2), fov=[[-50, -50, -4], [50, 50, 2]])))
+        saved = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            for k in range(len(frames)):
+                mod.post_processing(k)
+        finally:
+            torch.Tensor.cuda = saved
+        for k, (scan, pred, bf, pose) in enumerate(frames):
+            out["inst_f%d_in_sha" % k] = np.array(sha(scan, pred, bf, pose))
+            out["inst_f%d_refined" % k] = np.fromfile(dirs["refined"] + "%06d.label" % k, dtype=np.int32)
+    # what the fixture exercises (checked here so that a change of the generator cannot silently lose a case)
+    from oracle import ops_np
+    from streammos_amd import preprocess
+    stats = ops_np.instance_cluster_stats(frames[9][0], frames[9][1], frames[9][2])
+    sizes = sorted(s["points"] for s in stats)
+    assert 30 in sizes and 31 in sizes, sizes
+    del preprocess
+
+
 def main():
     ns = ref_import.import_reference()
     torch.set_num_threads(8)
     for name, fn, needs_ns in (("ops_voxel_maxpool", gen_voxel_maxpool, True), ("ops_bilinear", gen_bilinear, True),
                                ("ops_msda", gen_msda, True), ("ops_voting", gen_voting, True),
                                ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True),
-                               ("losses", gen_losses, True), ("seg", gen_seg, True)):
+                               ("losses", gen_losses, True), ("seg", gen_seg, True), ("instance", gen_instance, True)):
         out = {}
         fn(ns, out) if needs_ns else fn(out)
         path = os.path.join(HERE, name + ".npz")

@@ -126,6 +126,25 @@ def test_instance_voter_matches_oracle():
     assert changed > 0          # the instance stage did overrule the voxel vote somewhere
 
 
+def test_instance_voter_matches_reference_golden(golden):
+    """The device path (DBSCAN, box vote, voxel vote: csrc/instance.hip, csrc/vote.hip) against the label files the
+    REFERENCE's post_processing() wrote for the 10-frame fixture sequence (tests/golden/instance.npz): bit-exact."""
+    from tests import cases
+    from tests.util import check_inputs
+    g = golden("instance")
+    frames = cases.instance_sequence()
+    voter = streaming.InstanceVoter(DEV)            # window 8, LUT {0: 0, 1: 9, 2: 251}
+    got = {}
+    for fid, (scan, pred, bf, pose) in enumerate(frames):
+        check_inputs(g, "inst_f%d_in_sha" % fid, scan, pred, bf, pose)
+        for k, lab in voter.push(torch.from_numpy(scan).to(DEV), torch.from_numpy(pred).to(DEV), pose, torch.from_numpy(bf).to(DEV)):
+            got[k] = lab.cpu().numpy()
+    assert sorted(got) == list(range(len(frames)))
+    for fid in range(len(frames)):
+        want = g["inst_f%d_refined" % fid]
+        assert np.array_equal(got[fid], want), (fid, int((got[fid] != want).sum()))
+
+
 def test_instance_voter_needs_bf_labels():
     voter = streaming.InstanceVoter(DEV)
     with pytest.raises(RuntimeError, match="_bf"):

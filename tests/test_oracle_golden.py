@@ -105,3 +105,24 @@ def test_e2e_oracle_matches_reference(golden):
         np.testing.assert_allclose(memory[:, ::8, ::4, ::4].numpy(), g["e2e_f%d_mem_sub" % i], rtol=0, atol=2e-4)
         aux = torch.stack((a0, a1, a2))[:, :, :, ::8, ::8].numpy()
         np.testing.assert_allclose(aux, g["e2e_f%d_aux_sub" % i], rtol=0, atol=1e-4 * np.abs(g["e2e_f%d_aux_sub" % i]).max())
+
+
+def test_instance_voting_matches_reference(golden):
+    """Row f3 pinned: the oracle's instance_vote_frame against the label files the reference's own post_processing()
+    (voxel_instance_voting.py:195-270, extracted and run by tests/golden/make_golden.py::gen_instance) wrote for a 10-frame
+    synthetic sequence -- both history branches (frames < 8 look at frames 0..7 except themselves), a 30- and a 31-point
+    cluster, the sum-of-labels tie (4 x 1 vs 2 x 2 -> static), the minority win (3 x 1 vs 2 x 2 -> moving), a cluster
+    outside the voting crop (empty box -> static), cluster points exactly on the box faces.  Bit-exact."""
+    from streammos_amd import preprocess, streaming
+    g = golden("instance")
+    frames = cases.instance_sequence()
+    lut = np.zeros(256, dtype=np.int32)
+    lut[1], lut[2] = 9, 251
+    for fid, (scan, pred, bf, pose) in enumerate(frames):
+        check_inputs(g, "inst_f%d_in_sha" % fid, scan, pred, bf, pose)
+        inv = np.linalg.inv(pose)
+        hist = streaming.vote_history_ids(fid, 8)
+        hp = np.concatenate([preprocess.pose_align(frames[h][0], inv.dot(frames[h][3])) for h in hist], 0)
+        hl = np.concatenate([frames[h][1] for h in hist], 0)
+        got = lut[ops_np.instance_vote_frame(scan, pred, bf, hp, hl)]
+        assert np.array_equal(got, g["inst_f%d_refined" % fid]), fid
