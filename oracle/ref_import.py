@@ -11,7 +11,8 @@ Recipe:
     called for CPU tensors)
   * ``MultiScaleDeformableAttention`` -> module whose ms_deform_attn_forward is the
     reference's own ms_deform_attn_core_pytorch (deformattn/functions/ms_deform_attn_func.py:41-61;
-    the equivalence of the two is what deformattn/test.py:31-60 asserts)
+    the equivalence of the two is what deformattn/test.py:31-60 asserts) and whose
+    ms_deform_attn_backward is its autograd derivative (deformattn/test.py:63-78, gradcheck)
   * ``cv2`` -> empty module (imported at utils/boundary_loss.py:4, unused on this path)
 """
 import ast
@@ -67,6 +68,18 @@ def import_reference():
         return _f.ms_deform_attn_core_pytorch(value, shapes, loc, w).reshape(n, lq, -1)
 
     msda.ms_deform_attn_forward = _fwd
+
+    def _bwd(value, shapes, lsi, loc, w, grad_output, step):
+        # the CUDA backward (deformattn/src/cuda/ms_deform_im2col_cuda.cuh:301-920) as the autograd derivative of the
+        # reference's own ms_deform_attn_core_pytorch -- the pair deformattn/test.py:63-78 holds together with gradcheck
+        import torch
+        n, lq = loc.shape[0], loc.shape[1]
+        with torch.enable_grad():
+            v, l, a = (t.detach().requires_grad_(True) for t in (value, loc, w))
+            y = _f.ms_deform_attn_core_pytorch(v, shapes, l, a).reshape(n, lq, -1)
+            return torch.autograd.grad(y, (v, l, a), grad_output)
+
+    msda.ms_deform_attn_backward = _bwd
 
     import deep_point
     import networks.backbone

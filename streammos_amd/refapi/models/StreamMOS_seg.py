@@ -65,3 +65,13 @@ class AttNet(_base.AttNet):
             loss, memory = self.single_forward(step, query_embed_store=memory, use_query_store=i > 0, return_query=True)
             total = total + loss
         return total / 3
+
+
+def freeze_for_stage2(model):
+    """The stage-2 recipe of train_StreamMOS_seg.py:165-174: every parameter frozen except the `refine` head (the
+    stage-1 checkpoint is loaded with strict=False before).  Returns the trainable parameters."""
+    for p in model.parameters():
+        p.requires_grad = False
+    for p in model.refine.parameters():
+        p.requires_grad = True
+    return [p for p in model.parameters() if p.requires_grad]

@@ -210,3 +210,31 @@ def instance_sequence(n_frames=10):
         frames.append((np.ascontiguousarray(scan[perm]), np.concatenate(preds)[perm], np.concatenate(bfs)[perm],
                        synth.synthetic_pose(k)))
     return frames
+
+
+def training_batch():
+    """The `batch` dict of AttNet.forward (models/StreamMOS.py:155-179; _seg: models/StreamMOS_seg.py:173-196): three
+    chained samples `_0.._2` of the small e2e sequence (B=2, T=3, N=2048) with seeded per-point targets, BEV targets and
+    movable-object (`_bf`) targets in {0, 1, 2} (0 = ignored by the losses)."""
+    r = _rng(606)
+    batch = {}
+    for i, f in enumerate(e2e_frames(3)):
+        for k, v in f.items():
+            batch["%s_%d" % (k, i)] = v
+        batch["pcds_target_%d" % i] = r.integers(0, 3, (2, E2E_POINTS, 1)).astype(np.int64)
+        batch["pcds_bev_target_%d" % i] = r.integers(0, 3, (2, 256, 256, 1)).astype(np.int64)
+        batch["pcds_bf_target_%d" % i] = r.integers(0, 3, (2, E2E_POINTS, 1)).astype(np.int64)
+    return batch
+
+
+# parameters whose gradients the training fixture stores (stage 1): the first point MLP conv (reached through the
+# VoxelMaxPool backward), a conv of every BEV stage, the deformable-attention projections (through the sampler's backward),
+# the learned memory embedding (through the 3-frame chain), the point head
+TRAINING_GRAD_KEYS = (
+    "point_pre.layer.0.layer.1.weight", "bev_net.header_bev.0.conv_branch.0.weight", "bev_net.res1_bev.2.layer.0.weight",
+    "bev_net.res2.1.layer.3.weight", "bev_net.header_rv.1.layer.0.weight",
+    "bev_net.deformattn_module.deformattn_layers.0.cross_attn.sampling_offsets.weight",
+    "bev_net.deformattn_module.deformattn_layers.1.cross_attn.value_proj.weight",
+    "bev_net.deformattn_module.deformattn_layers.0.linear1.weight", "bev_net.query_embed.weight",
+    "bev_net.conv_1.conv.weight", "bev_net.aux_head2.weight", "point_post.merge_layer.0.weight", "pred_layer.pred_layer.0.weight",
+    "pred_layer.pred_layer.0.bias")

@@ -248,13 +248,76 @@ def gen_instance(ns, out):
     del preprocess
 
 
+def _grad_summary(out, prefix, model, keys):
+    named = dict(model.named_parameters())
+    for k in keys:
+        g = named[k].grad
+        flat = g.detach().reshape(-1)
+        out["%s_grad_norm_%s" % (prefix, k)] = np.array(flat.double().norm().item())
+        out["%s_grad_head_%s" % (prefix, k)] = flat[:: max(1, flat.numel() // 512)][:512].numpy().copy()
+
+
+def gen_training(ns, out):
+    """Row f2: loss and gradients of one training step of the reference on CPU.
+    stage 1: AttNet.forward (models/StreamMOS.py:155-179; three chained samples, OHEM-CE + 3 x Lovasz on the points and the
+             three BEV heads), (a) in eval mode (BatchNorm running statistics, no dropout: fully deterministic), (b) in train
+             mode (BatchNorm batch statistics + running-statistics update) with the dropout masks removed
+             (torch.nn.functional.dropout patched to the identity for the call: the masks depend on the device's generator).
+    stage 2: StreamMOS_seg.AttNet.forward with everything but `refine.*` frozen as train_StreamMOS_seg.py:165-174 does;
+             loss only on bf_pred_cls (models/StreamMOS_seg.py:164-171)."""
+    import contextlib
+    import io
+    import torch.nn.functional as F
+    import models.StreamMOS_seg as seg
+    import config.StreamMOS_seg as seg_cfg
+    from streammos_amd import synth
+    batch = {k: torch.from_numpy(v) for k, v in cases.training_batch().items()}
+    out["train_in_sha"] = np.array(sha(*[batch[k].numpy() for k in sorted(batch)]))
+
+    def identity_dropout(x, p=0.5, training=True, inplace=False):
+        return x
+
+    for mode in ("eval", "train"):
+        model = ns.StreamMOS.AttNet(ns.config.get_config()[2])
+        model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+        model.train(mode == "train")
+        saved = F.dropout
+        F.dropout = identity_dropout if mode == "train" else saved
+        try:
+            loss = model(batch)
+            loss.backward()
+        finally:
+            F.dropout = saved
+        out["stage1_%s_loss" % mode] = np.array(loss.item())
+        _grad_summary(out, "stage1_%s" % mode, model, cases.TRAINING_GRAD_KEYS)
+        if mode == "train":        # BatchNorm running statistics after the three chained forwards
+            sd = model.state_dict()
+            for k in ("point_pre.layer.0.layer.2.running_mean", "bev_net.res2.1.layer.1.running_var", "bev_net.conv_1.bn.running_mean"):
+                out["stage1_train_bn_%s" % k] = sd[k].numpy().copy()
+
+    model = seg.AttNet(seg_cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    for p_ in model.parameters():                        # train_StreamMOS_seg.py:165-174
+        p_.requires_grad = False
+    for p_ in model.refine.parameters():
+        p_.requires_grad = True
+    model.eval()
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference prints the input shape
+        loss = model(batch)
+    loss.backward()
+    out["stage2_eval_loss"] = np.array(loss.item())
+    with_grad = [k for k, p_ in model.named_parameters() if p_.grad is not None]
+    out["stage2_params_with_grad"] = np.array(with_grad)
+    _grad_summary(out, "stage2_eval", model, with_grad)
+
+
 def main():
     ns = ref_import.import_reference()
     torch.set_num_threads(8)
     for name, fn, needs_ns in (("ops_voxel_maxpool", gen_voxel_maxpool, True), ("ops_bilinear", gen_bilinear, True),
                                ("ops_msda", gen_msda, True), ("ops_voting", gen_voting, True),
                                ("preprocess", gen_preprocess, False), ("e2e", gen_e2e, True),
-                               ("losses", gen_losses, True), ("seg", gen_seg, True), ("instance", gen_instance, True)):
+                               ("losses", gen_losses, True), ("seg", gen_seg, True), ("instance", gen_instance, True), ("training", gen_training, True)):
         out = {}
         fn(ns, out) if needs_ns else fn(out)
         path = os.path.join(HERE, name + ".npz")

@@ -72,3 +72,87 @@ def test_one_chained_training_step_runs_and_updates_weights():
     opt.step()
     assert (model.pred_layer.pred_layer[0].weight - before).abs().max().item() > 0
     assert (model.bev_net.query_embed.weight - q_before).abs().max().item() > 0
+
+
+def _check_grads(g, prefix, model, keys, tol):
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k in keys:
+        grad = named[k].grad
+        assert grad is not None, k
+        flat = grad.detach().reshape(-1)
+        want_norm = float(g["%s_grad_norm_%s" % (prefix, k)])
+        want_head = g["%s_grad_head_%s" % (prefix, k)]
+        got_head = flat[:: max(1, flat.numel() // 512)][:512].cpu().numpy()
+        scale = max(np.abs(want_head).max(), want_norm / max(flat.numel(), 1) ** 0.5, 1e-12)
+        err = max(abs(flat.double().norm().item() - want_norm) / max(want_norm, 1e-12),
+                  np.abs(got_head - want_head).max() / scale)
+        worst = max(worst, err)
+        assert err <= tol, (k, err)
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_stage1_training_step_matches_reference_golden(golden, mode):
+    """Loss and gradients of AttNet.forward (three chained samples; OHEM-CE + 3 x Lovasz on points and BEV heads) against
+    the reference run on CPU (tests/golden/make_golden.py::gen_training): through the HIP VoxelMaxPool / sampler backward
+    kernels, MIOpen conv backward and the memory chain.  eval: BatchNorm running statistics; train: batch statistics +
+    running-statistics update, dropout masks removed on both sides (they depend on the device's generator)."""
+    import torch.nn.functional as F
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    from tests.util import check_inputs
+    g = golden("training")
+    nb = cases.training_batch()
+    check_inputs(g, "train_in_sha", *[nb[k] for k in sorted(nb)])
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in nb.items()}
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    model = model.to(DEV).train(mode == "train")
+    saved = F.dropout
+    if mode == "train":
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    try:
+        loss = model(batch)
+        loss.backward()
+    finally:
+        F.dropout = saved
+    want = float(g["stage1_%s_loss" % mode])
+    rel = abs(loss.item() - want) / abs(want)
+    worst = _check_grads(g, "stage1_%s" % mode, model, cases.TRAINING_GRAD_KEYS, 2e-3)
+    print("stage 1 (%s): loss %.6g vs %.6g (rel %.1e), worst gradient deviation %.1e" % (mode, loss.item(), want, rel, worst))
+    assert rel <= 1e-4
+    if mode == "train":
+        sd = model.state_dict()
+        for k in ("point_pre.layer.0.layer.2.running_mean", "bev_net.res2.1.layer.1.running_var", "bev_net.conv_1.bn.running_mean"):
+            ref = g["stage1_train_bn_%s" % k]
+            assert np.abs(sd[k].cpu().numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), k
+
+
+def test_stage2_training_step_matches_reference_golden(golden):
+    """StreamMOS_seg.AttNet.forward with everything but `refine.*` frozen (train_StreamMOS_seg.py:165-174): the loss is
+    taken on bf_pred_cls only (models/StreamMOS_seg.py:164-171), exactly the eight `refine` parameters receive a gradient,
+    and loss and gradients equal the reference's."""
+    from streammos_amd.refapi.config import StreamMOS_seg as seg_cfg
+    from streammos_amd.refapi.models import StreamMOS_seg
+    g = golden("training")
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in cases.training_batch().items()}
+    model = StreamMOS_seg.AttNet(seg_cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    trainable = StreamMOS_seg.freeze_for_stage2(model)
+    assert len(trainable) == 8
+    model = model.to(DEV).eval()
+    loss = model(batch)
+    loss.backward()
+    with_grad = [k for k, p in model.named_parameters() if p.grad is not None]
+    assert with_grad == [str(k) for k in g["stage2_params_with_grad"]]
+    want = float(g["stage2_eval_loss"])
+    rel = abs(loss.item() - want) / abs(want)
+    worst = _check_grads(g, "stage2_eval", model, with_grad, 2e-3)
+    print("stage 2: loss %.6g vs %.6g (rel %.1e), worst gradient deviation %.1e" % (loss.item(), want, rel, worst))
+    assert rel <= 1e-4
+    # one optimiser step moves the refine head and nothing else
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.optim.SGD(trainable, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-3).step()
+    moved = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
+    assert moved and all(k.startswith("refine.") for k in moved)
