@@ -7,66 +7,77 @@
 // [S, M, D].  The (location, weight) pairs of a head are the same for all of its D lanes: in the
 // D == 32 specialisation each 32-lane half loads them once (lane p < L*P takes sample p) and the
 // bilinear corner offsets / weights are broadcast with wavefront shuffles instead of being re-read
-// and re-derived by every lane.  The generic kernel keeps one lane per output element with the
-// reference's loop structure, for any D, L, P.
+// and re-derived by every lane.  The kernel for any other D, L, P (and for float64) works the same way with a whole
+// wave per head (msda_fwd_heads).
 #include "smos_common.h"
 
 namespace smos {
 
+// Any D, L, P, float or double: one WAVE per (batch, query, head).  Lane s of the wave owns sample s of the head (its
+// level, location, attention weight, the four corner offsets and bilinear weights -- computed once per head, not once per
+// output channel), lane c owns channel c: the sample loop broadcasts a sample's eight numbers with wavefront shuffles
+// and every tap is one contiguous row of D values of the [S, M, D] value tensor.  Heads wider than 64 channels take
+// several passes over the channels, heads with more than 64 samples several chunks of samples.  Per output element the
+// arithmetic is that of the reference kernel (ms_deform_im2col_cuda.cuh:237-299): ((w1 v1 + w2 v2) + w3 v3 + w4 v4) * a,
+// summed over the samples in order; a sample outside (-1, H) x (-1, W) contributes nothing, a corner outside the map 0.
 template <typename T>
-__device__ __forceinline__ T bilinear_tap(const T* __restrict__ v, int H, int W, int64_t wstride, T h, T w) {
-  // reference: ms_deform_im2col_cuda.cuh:38-83 (value pointer already offset to head/channel)
-  const int h_low = (int)floor(h), w_low = (int)floor(w);
-  const int h_high = h_low + 1, w_high = w_low + 1;
-  const T lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
-  const int64_t hstride = (int64_t)W * wstride;
-  T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-  if (h_low >= 0 && w_low >= 0) v1 = v[h_low * hstride + w_low * wstride];
-  if (h_low >= 0 && w_high <= W - 1) v2 = v[h_low * hstride + w_high * wstride];
-  if (h_high <= H - 1 && w_low >= 0) v3 = v[h_high * hstride + w_low * wstride];
-  if (h_high <= H - 1 && w_high <= W - 1) v4 = v[h_high * hstride + w_high * wstride];
-  const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void msda_fwd_generic(const T* __restrict__ value,
-                                                           const int64_t* __restrict__ shapes,
-                                                           const int64_t* __restrict__ lsi,
-                                                           const T* __restrict__ loc, const T* __restrict__ attn,
-                                                           T* __restrict__ out, int64_t total, int S, int M, int D,
-                                                           int L, int Lq, int P) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = idx;
-    const int c = (int)(t % D);
-    t /= D;
-    const int64_t sampling_index = t;  // (b*Lq + q)*M + m
-    const int m = (int)(t % M);
-    t /= M;
-    t /= Lq;
-    const int64_t b = t;
-    int64_t wptr = sampling_index * L * P;
-    int64_t lptr = wptr << 1;
-    const int64_t wstride = (int64_t)M * D;
-    T col = 0;
-    for (int l = 0; l < L; ++l) {
-      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      const T* v = value + (b * S + lsi[l]) * wstride + (int64_t)m * D + c;
-      for (int p = 0; p < P; ++p) {
-        const T loc_w = loc[lptr], loc_h = loc[lptr + 1], wt = attn[wptr];
-        const T h_im = loc_h * H - (T)0.5, w_im = loc_w * W - (T)0.5;
-        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) col += bilinear_tap<T>(v, H, W, wstride, h_im, w_im) * wt;
-        wptr += 1;
-        lptr += 2;
+__global__ __launch_bounds__(kBlock) void msda_fwd_heads(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                         const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                                                         const T* __restrict__ attn, T* __restrict__ out,
+                                                         int64_t n_heads_total, int S, int M, int D, int L, int Lq, int P) {
+  const int lane = threadIdx.x & 63;
+  const int LP = L * P;
+  const int64_t wstride = (int64_t)M * D;
+  for (int64_t hq = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; hq < n_heads_total;
+       hq += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int m = (int)(hq % M);
+    const int64_t b = hq / ((int64_t)M * Lq);
+    const T* vb = value + (b * S) * wstride + (int64_t)m * D;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+      const int c = c0 + lane;
+      T col = 0;
+      for (int s0 = 0; s0 < LP; s0 += 64) {
+        T cw[4] = {0, 0, 0, 0}, aw = 0;
+        int co[4] = {-1, -1, -1, -1};
+        const int smp = s0 + lane;
+        if (smp < LP) {
+          const int l = smp / P;
+          const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+          const T loc_w = loc[(hq * LP + smp) * 2], loc_h = loc[(hq * LP + smp) * 2 + 1];
+          aw = attn[hq * LP + smp];
+          const T h_im = loc_h * H - (T)0.5, w_im = loc_w * W - (T)0.5;
+          if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+            const int y0 = (int)floor(h_im), x0 = (int)floor(w_im);
+            const T fy = h_im - y0, fx = w_im - x0, gy = 1 - fy, gx = 1 - fx;
+            const int base = (int)lsi[l];
+            const bool top = y0 >= 0, bot = y0 + 1 <= H - 1, lft = x0 >= 0, rgt = x0 + 1 <= W - 1;
+            co[0] = (top && lft) ? base + y0 * W + x0 : -1;
+            co[1] = (top && rgt) ? base + y0 * W + x0 + 1 : -1;
+            co[2] = (bot && lft) ? base + (y0 + 1) * W + x0 : -1;
+            co[3] = (bot && rgt) ? base + (y0 + 1) * W + x0 + 1 : -1;
+            cw[0] = gy * gx; cw[1] = gy * fx; cw[2] = fy * gx; cw[3] = fy * fx;
+          }
+        }
+        const int n = LP - s0 < 64 ? LP - s0 : 64;
+        for (int q = 0; q < n; ++q) {
+          T tap = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int o = __shfl(co[k], q);
+            const T w = __shfl(cw[k], q);
+            const T v = (o >= 0 && c < D) ? vb[(int64_t)o * wstride + c] : (T)0;
+            tap += w * v;
+          }
+          col += tap * __shfl(aw, q);
+        }
       }
+      if (c < D) out[hq * D + c] = col;
     }
-    out[idx] = col;
   }
 }
 
 // D == 32, L*P <= 8, float32: one 32-lane half per (b, q, m); shuffle-broadcast sample metadata.
-// Arithmetic per output element is the same expression tree as the generic kernel.
+// Arithmetic per output element is the same expression tree as msda_fwd_heads.
 __global__ __launch_bounds__(kBlock) void msda_fwd_d32(const float* __restrict__ value,
                                                        const int64_t* __restrict__ shapes,
                                                        const int64_t* __restrict__ lsi, const float* __restrict__ loc,
@@ -297,14 +308,14 @@ extern "C" int smos_msda_fwd(const void* value, const int64_t* spatial_shapes, c
                          (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc,
                          (const float*)attn_weight, (float*)out, heads, (int)S, (int)M, (int)L, (int)Lq, (int)P);
     } else {
-      hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(grid_for(total, kBlock, 256 * 16)), dim3(kBlock), 0, s,
+      hipLaunchKernelGGL(msda_fwd_heads<float>, dim3(grid_for(N * Lq * M * 64, kBlock, 256 * 16)), dim3(kBlock), 0, s,
                          (const float*)value, spatial_shapes, level_start_index, (const float*)sampling_loc,
-                         (const float*)attn_weight, (float*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
+                         (const float*)attn_weight, (float*)out, N * Lq * M, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
     }
   } else {
-    hipLaunchKernelGGL(msda_fwd_generic<double>, dim3(grid_for(total, kBlock, 256 * 16)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(msda_fwd_heads<double>, dim3(grid_for(N * Lq * M * 64, kBlock, 256 * 16)), dim3(kBlock), 0, s,
                        (const double*)value, spatial_shapes, level_start_index, (const double*)sampling_loc,
-                       (const double*)attn_weight, (double*)out, total, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
+                       (const double*)attn_weight, (double*)out, N * Lq * M, (int)S, (int)M, (int)D, (int)L, (int)Lq, (int)P);
   }
   return check_launch("msda_fwd");
 }

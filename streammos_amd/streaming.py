@@ -206,13 +206,10 @@ class StreamRunner:
     _KEYS = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
 
     def _capture(self, dev):
-        # capture-safe engine configuration: under MIOpen's solver search the channels-last convs resolve to
-        # composable-kernel grouped-conv solvers whose argument staging does not survive graph replay (observed: 2 %
-        # wrong logits); the NCHW engine with MIOpen's default (immediate-mode) solvers replays bit-exactly.
-        saved = (self.model.engine_layout, self.model.engine_miopen_search)
-        self.model.engine_layout = "nchw"
-        self.model.engine_miopen_search = False
-        self.model.invalidate_engine()
+        # The channels-last engine is captured as it stands: every convolution is the library's own kernel
+        # (csrc/conv_igemm.hip), so no MIOpen solver is replayed.  (Round 1 pinned the NCHW engine here because MIOpen's
+        # composable-kernel grouped-conv solvers gave ~2 % wrong logits under replay; the cause was never established and
+        # those solvers are no longer on the path.)
         with torch.no_grad():
             eng = self.model._engine_for(dev["pcds_xyzi"])
         if eng is None:
@@ -250,8 +247,6 @@ class StreamRunner:
             self._groups.append({"in": g_in, "mem": g_mem, "graphs": graphs, "slice": sl,
                                  "stream": torch.cuda.Stream(self.device)})
         eng.ws_tag = 0
-        # the caller's model goes back to its own configuration; its next eager call rebuilds its engine
-        self.model.engine_layout, self.model.engine_miopen_search = saved
         self._g_shape = tuple(dev["pcds_xyzi"].shape)
         self._g_pred = torch.empty((v,) + tuple(self._groups[0]["graphs"][True][1].shape[1:]), dtype=torch.float32,
                                    device=self.device)

@@ -316,9 +316,10 @@ def test_graph_replay_equals_eager(model):
         res[graph] = outs
     for other in (True, 2):
         for (p0, l0, r0), (p1, l1, r1) in zip(res[False], res[other]):
-            # eager = channels-last engine with solver search, graph = NCHW engine with default solvers
-            assert (p0 - p1).abs().max().item() <= 3e-4 * p0.abs().max().item()
-            assert (l0 == l1).float().mean().item() >= 0.9995 and (r0 == r1).float().mean().item() >= 0.9995
+            # the same channels-last engine, replayed instead of launched: own convs are deterministic and batch-independent,
+            # only the library GEMMs of the attention block may choose another kernel for the half batch of split=2
+            assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
+            assert torch.equal(l0, l1) and torch.equal(r0, r1)
 
 
 def test_concurrent_streams_equal_separate_streams(model):

@@ -608,3 +608,57 @@ def test_conv_cl_is_deterministic_and_batch_independent():
     b = ops.conv_cl(x, wp, None, 1, 64, (3, 3), mt=2)
     c = ops.conv_cl(x[1:2], wp, None, 1, 64, (3, 3), mt=2)
     assert torch.equal(a, b) and torch.equal(a[1:2], c)
+
+
+@pytest.mark.parametrize("name", ["basic", "scaled_neg", "dim3", "relu_like"])
+def test_pybind_name_point_deep_cuda_kernel_with_the_references_argument_lists(golden, name):
+    """`point_deep.cuda_kernel.voxel_maxpooling_forward / _backward` called exactly as the reference's autograd Function
+    calls them (deep_point/__init__.py:25-44, :48-61): caller-allocated zero / -1 filled buffers and the four small META
+    TENSORS ON THE DEVICE (int64 sizes / strides / output size, float32 scale).  Bit-exact against the reference's output
+    and gradient."""
+    from streammos_amd.refapi.point_deep import cuda_kernel
+    g = golden("ops_voxel_maxpool")
+    feat, ind, output_size, scale_rate = cases.voxel_maxpool_cases()[name]
+    pcds_feat, pcds_ind = _t(feat).unsqueeze(-1), _t(ind).unsqueeze(-1)
+    voxel_out_shape = [pcds_feat.size(0), pcds_feat.size(1)] + list(output_size)
+    voxel_out = torch.zeros(voxel_out_shape, dtype=pcds_feat.dtype, device=pcds_feat.device)
+    voxel_max_idx = torch.full([pcds_ind.size(0), pcds_ind.size(1)], -1, dtype=torch.int64, device=pcds_feat.device)
+    voxel_out_size_pt = torch.LongTensor(voxel_out_shape).to(pcds_feat.device)
+    voxel_out_stride_pt = torch.LongTensor(voxel_out.stride()).to(pcds_feat.device)
+    output_size_pt = voxel_out_size_pt[2:]
+    scale_rate_pt = torch.FloatTensor(list(scale_rate)).to(pcds_feat.device)
+    cuda_kernel.voxel_maxpooling_forward(pcds_feat, pcds_ind, voxel_out, voxel_max_idx, voxel_out_size_pt, voxel_out_stride_pt,
+                                         output_size_pt, scale_rate_pt)
+    assert np.array_equal(voxel_out.cpu().numpy(), g["vmp_%s_out" % name])
+    assert np.array_equal((voxel_max_idx >= 0).cpu().numpy(), ops_np.voxel_cell_index(ind, output_size, scale_rate) >= 0)
+    grad_voxel_out = _t(cases.grad_like(tuple(voxel_out.shape), name)).contiguous()
+    grad_pcds_feat = torch.zeros(pcds_feat.shape, dtype=grad_voxel_out.dtype, device=grad_voxel_out.device)
+    cuda_kernel.voxel_maxpooling_backward(pcds_feat, pcds_ind, voxel_out, voxel_max_idx, grad_pcds_feat, grad_voxel_out,
+                                          voxel_out_size_pt, voxel_out_stride_pt, output_size_pt, scale_rate_pt)
+    assert np.array_equal(grad_pcds_feat[..., 0].cpu().numpy(), g["vmp_%s_grad" % name])
+    with pytest.raises(RuntimeError):                                                   # CHECK_INPUT: CUDA + contiguous
+        cuda_kernel.voxel_maxpooling_forward(pcds_feat.cpu(), pcds_ind, voxel_out, voxel_max_idx, voxel_out_size_pt,
+                                             voxel_out_stride_pt, output_size_pt, scale_rate_pt)
+
+
+def test_pybind_name_msda_module_with_the_references_argument_lists(golden):
+    """`MultiScaleDeformableAttention.ms_deform_attn_forward / _backward` called as MSDeformAttnFunction calls them
+    (deformattn/functions/ms_deform_attn_func.py:21-38): int64 shape / level-start tensors on the device, im2col_step as
+    an int; forward against the reference's golden output, backward against autograd of the torch formulation."""
+    from streammos_amd.refapi import MultiScaleDeformableAttention as MSDA
+    from streammos_amd.refapi.deformattn.functions import ms_deform_attn_core_pytorch
+    g = golden("ops_msda")
+    value, shapes, lsi, loc, attn = cases.msda_cases()["reftest"]
+    tv, ts, ti, tl, ta = _t(value), _t(shapes), _t(lsi), _t(loc), _t(attn)
+    out = MSDA.ms_deform_attn_forward(tv, ts, ti, tl, ta, 2)
+    np.testing.assert_allclose(out.cpu().numpy(), g["msda_reftest_out32"], rtol=1e-5, atol=1e-7)
+    grad_output = torch.randn(out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    gv, gl, ga = MSDA.ms_deform_attn_backward(tv, ts, ti, tl, ta, grad_output, 2)
+    rv, rl, ra = (t.clone().requires_grad_(True) for t in (tv, tl, ta))
+    ms_deform_attn_core_pytorch(rv, ts, rl, ra).backward(grad_output.view(out.shape[0], out.shape[1], -1))
+    for got, want in ((gv, rv.grad), (gl, rl.grad), (ga, ra.grad)):
+        assert (got - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-6)
+    with pytest.raises(RuntimeError, match="CPU"):
+        MSDA.ms_deform_attn_forward(tv.cpu(), ts, ti, tl, ta, 2)
+    with pytest.raises(RuntimeError):                                                   # batch % im2col_step
+        MSDA.ms_deform_attn_forward(torch.cat((tv, tv, tv)), ts, ti, torch.cat((tl, tl, tl)), torch.cat((ta, ta, ta)), 2)
