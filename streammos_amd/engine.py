@@ -156,7 +156,6 @@ class InferenceEngine:
         self._lsi = None
         self._hw = None
         self.miopen_search = True
-        self.ws_tag = 0
 
     # ---- parameter extraction -----------------------------------------------------------
     def _block(self, m):
@@ -243,12 +242,13 @@ class InferenceEngine:
 
     def _block_ws(self, p, n_floats):
         """Scratch of one channel-attention block (plane sums written by one kernel, read by the next).  Keyed by
-        (block, HIP stream, ws_tag): blocks of different pipeline stages run concurrently on different streams, the same
+        (block, HIP stream, scratch namespace): blocks of different pipeline stages run concurrently on different streams, the same
         block may run on two streams at once (encode(t) on the main stream next to encode(t+1) on the side stream), and
         hipGraphs captured from one engine for several TTA groups replay concurrently with the addresses baked in
-        (``ws_tag`` = group index, set by StreamRunner._capture) -- a shared scratch would be a data race in each case."""
+        (namespace = group index, ops.set_workspace_namespace in StreamRunner._capture) -- a shared scratch would be a data
+        race in each case."""
         table = p.__dict__.setdefault("ws", {})
-        key = (torch.cuda.current_stream(self.device).cuda_stream, self.ws_tag)
+        key = (torch.cuda.current_stream(self.device).cuda_stream, ops._ws_namespace)
         ws = table.get(key)
         if ws is None or ws.numel() < n_floats:
             ws = table[key] = torch.zeros(n_floats, dtype=torch.float32, device=self.device)

@@ -11,6 +11,17 @@ from . import _lib, profiling
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 _flag_ws = {}
+_ws_namespace = 0
+
+
+def set_workspace_namespace(tag):
+    """Per-stream scratch (``_stream_workspace``, ``_flag``) is keyed by (device, HIP stream, namespace).  Work that is
+    captured on ONE stream but replayed concurrently on several (the TTA groups of StreamRunner(graph=True, split=k) all use
+    torch's capture stream) selects a namespace per group while it is being captured, so that the groups' graphs do not
+    share scratch.  Returns the previous namespace."""
+    global _ws_namespace
+    prev, _ws_namespace = _ws_namespace, tag
+    return prev
 
 
 def _stream(t):
@@ -26,7 +37,7 @@ def _require_cuda(name, *tensors):
 def _flag(device):
     """4-byte "saw a negative feature" scratch of the scatter; one per (device, stream) so that launches on different
     HIP streams never share it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, _ws_namespace)
     ws = _flag_ws.get(key)
     if ws is None:
         ws = torch.zeros(4, dtype=torch.int32, device=device)
@@ -562,7 +573,7 @@ def _stream_workspace(tag, shape, dtype, device, zero=False):
     the host has enqueued ahead of the GPU.  The returned view is valid until the next request with the same tag on the
     same stream (callers consume it within the frame).  zero=True: zero-filled when (re)allocated -- for buffers whose
     users leave them zero (the occupancy flags).  ``release_stream_workspaces`` frees them."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, dtype)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, dtype, _ws_namespace)
     need = 1
     for d in shape:
         need *= int(d)
@@ -572,10 +583,16 @@ def _stream_workspace(tag, shape, dtype, device, zero=False):
     return buf[:need].view(shape)
 
 
-def release_stream_workspaces(device=None, stream=None):
-    """Drops the per-stream scratch (all of it, or one device's / one HIP stream's); StreamRunner.close() calls this."""
+def release_stream_workspaces(device=None, stream=None, owner=None):
+    """Drops the per-stream scratch: all of it, one device's, one HIP stream's, or (owner = the id a graph runner put into
+    its namespace) what that runner's captured graphs use.  StreamRunner.close() calls this."""
     for key in list(_stem_ws):
-        if (device is None or key[0] == str(device)) and (stream is None or key[1] == stream):
+        ns = key[4]
+        owned = isinstance(ns, tuple) and len(ns) > 1 and ns[1] == owner
+        if owner is not None:
+            if owned:
+                del _stem_ws[key]
+        elif (device is None or key[0] == str(device)) and (stream is None or key[1] == stream):
             del _stem_ws[key]
 
 

@@ -220,9 +220,19 @@ class StreamRunner:
         per = v // k
         self._groups = []
         side = torch.cuda.Stream(self.device)
+        try:
+            self._capture_groups(dev, eng, k, per, side)
+        finally:
+            ops.set_workspace_namespace(0)
+        self._g_shape = tuple(dev["pcds_xyzi"].shape)
+        self._g_pred = torch.empty((v,) + tuple(self._groups[0]["graphs"][True][1].shape[1:]), dtype=torch.float32,
+                                   device=self.device)
+        self._graphs = True
+
+    def _capture_groups(self, dev, eng, k, per, side):
         for gi in range(k):
             sl = slice(gi * per, (gi + 1) * per)
-            eng.ws_tag = gi             # per-group scratch: the groups' graphs replay concurrently (engine._block_ws)
+            ops.set_workspace_namespace(("graph", id(self), gi))    # per-group scratch: the groups' graphs replay concurrently
             g_in = {key: dev[key][sl].clone() for key in self._KEYS}
             batch = {key: g_in[key].unsqueeze(0) for key in self._KEYS}
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -246,11 +256,6 @@ class StreamRunner:
                 graphs[first] = (g, pred)
             self._groups.append({"in": g_in, "mem": g_mem, "graphs": graphs, "slice": sl,
                                  "stream": torch.cuda.Stream(self.device)})
-        eng.ws_tag = 0
-        self._g_shape = tuple(dev["pcds_xyzi"].shape)
-        self._g_pred = torch.empty((v,) + tuple(self._groups[0]["graphs"][True][1].shape[1:]), dtype=torch.float32,
-                                   device=self.device)
-        self._graphs = True
 
     def _replay(self, dev):
         main = torch.cuda.current_stream(self.device)
@@ -282,6 +287,9 @@ class StreamRunner:
         ops.release_stream_workspaces(self.device, main)
         if self._side is not None:
             ops.release_stream_workspaces(self.device, self._side.cuda_stream)
+        if self._graphs is not None:                 # the captured graphs go first: their kernels use that scratch
+            self._graphs = self._groups = None
+            ops.release_stream_workspaces(owner=id(self))
 
     def upload(self, sample, raw_scan=None):
         """Host sample (streammos_amd.preprocess.build_sample) -> device-resident inputs."""
