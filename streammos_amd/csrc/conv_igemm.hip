@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
 
 #ifdef SMOS_CONV_STAMPS
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+  const unsigned long long clk0 = stamp_last, real0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll 1
   for (int g = 0; g < total; g += 4) {
@@ -363,8 +364,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     if (g + 3 < total) SMOS_STAGE(b3, b2, 3, 0, ae0, ae1, ae2, ae3);
   }
 #ifdef SMOS_CONV_STAMPS
-  if (a.stamps && lane == 0)
-    for (int k = 0; k < 9; ++k) a.stamps[((int64_t)blockIdx.x * 4 + wave) * 9 + k] = stamp_sum[k];
+  if (a.stamps && lane == 0) {
+    for (int k = 0; k < 9; ++k) a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + k] = stamp_sum[k];
+    // shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + 9] = __builtin_amdgcn_s_memtime() - clk0;
+    a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + 10] = __builtin_amdgcn_s_memrealtime() - real0;
+  }
 #endif
 }
 

@@ -22,14 +22,17 @@ for (cin, cout, k, hw, mt) in ((32, 32, (3, 3), (256, 256), 1), (128, 64, (3, 3)
     x = torch.randn(4, hw[0], hw[1], cin, device=dev).permute(0, 3, 1, 2)
     wt = torch.randn(cout, cin, *k, device=dev) * 0.05
     wp = ops.conv_prepare(wt, mt)
-    buf = torch.zeros(4 * 9 * 2048, dtype=torch.int64, device=dev)
+    buf = torch.zeros(4 * 11 * 2048, dtype=torch.int64, device=dev)
     os.environ["SMOS_CONV_STAMP_PTR"] = str(buf.data_ptr())
-    for _ in range(3):
+    for _ in range(int(os.environ.get("STAMP_LAUNCHES", "3"))):
         ops.conv_cl(x, wp, None, 1, cout, k, mt=mt)
     torch.cuda.synchronize()
-    s = buf.view(-1, 9).double()
+    s = buf.view(-1, 11).double()
     s = s[s.sum(1) > 0]
+    clock = (s[:, 9] / s[:, 10]).median().item() * 100.0
+    s = s[:, :9]
     tot = s.sum(1).mean().item()
+    print("   in-kernel shader clock %.0f MHz (median over waves, last of the launches)" % clock)
     print("cin %d cout %d k%s %dx%d mt%d: %d waves, %.0f cycles per wave (last launch)" % (cin, cout, k, hw[0], hw[1], mt, s.shape[0], tot))
     for i in order:
         print("   %-24s %5.1f %%" % (names[order.index(i)], 100 * s[:, i].mean().item() / tot))
