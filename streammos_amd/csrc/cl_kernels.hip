@@ -350,130 +350,6 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
   }
 }
 
-// ---- the same gather + max scatter with the target staged in LDS: no global atomic at all ----
-// The scatter above pays one 128 / 256-byte row atomic per (run of points in one cell): on scans whose neighbouring
-// returns jump between cells that is almost one atomic per point, 6-8 x the bytes the target map needs (PMC, round 1).
-// Here a block OWNS a tile of the target map (th x tw cells x kC channels in LDS, <= 128 KB).  Its 16 waves sweep the
-// target coordinates of all N points of the sample (8 bytes per point, L2-resident: a cheap filter), and only the points
-// that fall into the tile are gathered (four contiguous row reads, lane = channel) and max-reduced into the tile with LDS
-// atomics; the tile is then written once with plain 16-byte stores -- every cell of the map, so the caller's zero fill
-// becomes unnecessary.  Values are identical to gather_scatter_cl (same gather arithmetic, max is order-free; features
-// are >= 0 after ReLU, <= 0 never overrides the 0 of an empty cell, as there).  Point rows (pts_out) are emitted by the
-// block whose tile holds the point; points without a target cell by the sample's first tile.
-struct GsTileArgs {
-  GsClArgs g;
-  int th, tw, tiles_y, tiles_x;
-};
-
-template <int kC>
-__global__ __launch_bounds__(1024) void gather_scatter_tiles(GsTileArgs t) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const GsClArgs& a = t.g;
-  constexpr int kSub = 64 / kC;      // points a wave handles side by side (lane = channel inside a point)
-  constexpr int kU = 2;              // such steps in flight
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sub = lane / kC, ch = lane % kC;
-  int blk = blockIdx.x;
-  const int tx = blk % t.tiles_x;
-  blk /= t.tiles_x;
-  const int ty = blk % t.tiles_y, b = blk / t.tiles_y;
-  const int y0 = ty * t.th, x0 = tx * t.tw, ncell = t.th * t.tw;
-  for (int i = tid; i < ncell * (kC / 4); i += 1024) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  const bool strays = (ty == 0) && (tx == 0) && a.pts_out;         // this block also emits the rows of points without a cell
-  const float* gb = a.grid + (int64_t)b * a.Hg * a.Wg * a.gp + ch;
-  float* pb = a.pts_out ? a.pts_out + (int64_t)b * a.po_b + ch : nullptr;
-  const int runs = (a.N + 63) / 64;
-  for (int run = wave; run < runs; run += 16) {
-    const int n = run * 64 + lane;
-    // ---- filter: lane j <-> point j; where does it go?
-    int lc = -1;
-    bool mine = false;
-    if (n < a.N) {
-      const float* sr = a.scoord + ((int64_t)b * a.N + n) * a.Ks;
-      const float py = __fmul_rn(sr[0], a.ssy), px = __fmul_rn(sr[1], a.ssx);
-      const bool ok = (py > -1.0f) && (py < (float)a.Ho) && (px > -1.0f) && (px < (float)a.Wo);
-      const int cy = (int)py - y0, cx = (int)px - x0;
-      const bool in = ok && (unsigned)cy < (unsigned)t.th && (unsigned)cx < (unsigned)t.tw;
-      lc = in ? cy * t.tw + cx : -1;
-      mine = in || (strays && !ok);
-    }
-    unsigned long long mask = __ballot(mine);
-    if (mask == 0) continue;
-    // ---- taps of the points that are this block's (float32 position arithmetic of bilinear_gather.hip)
-    int off[4] = {-1, -1, -1, -1};
-    float wt[4] = {0.f, 0.f, 0.f, 0.f};
-    if (mine) {
-      const float* cr = a.gcoord + ((int64_t)b * a.N + n) * a.Kg;
-      const float iy = pix_cl(cr[0], a.gsy, a.Hg), ix = pix_cl(cr[1], a.gsx, a.Wg);
-      const float fy = floorf(iy), fx = floorf(ix);
-      const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
-      const bool fin = (iy > -2.0f) && (iy < (float)(a.Hg + 1)) && (ix > -2.0f) && (ix < (float)(a.Wg + 1));
-      const int yy0 = fin ? (int)fy : -5, xx0 = fin ? (int)fx : -5;
-      const float w4[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int y = yy0 + (k >> 1), xx = xx0 + (k & 1);
-        const bool in = (y >= 0) && (y < a.Hg) && (xx >= 0) && (xx < a.Wg);
-        off[k] = in ? y * a.Wg + xx : -1;
-        wt[k] = in ? w4[k] : 0.0f;
-      }
-    }
-    // ---- lane = channel: walk the set bits of the mask, kSub points side by side, kU steps in flight
-    while (mask) {
-      int src[kU];
-      bool live[kU];
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        int pick = -1;
-#pragma unroll
-        for (int sidx = 0; sidx < kSub; ++sidx) {
-          int j = -1;
-          if (mask) {
-            j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-          }
-          if (sidx == sub) pick = j;
-        }
-        live[u] = pick >= 0;
-        src[u] = live[u] ? pick : lane;
-      }
-      int o[kU][4], c[kU];
-      float w[kU][4], g[kU][4];
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          o[u][k] = __shfl(off[k], src[u]);
-          w[u][k] = __shfl(wt[k], src[u]);
-        }
-        c[u] = __shfl(lc, src[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[u][k] = (live[u] && o[u][k] >= 0) ? gb[(int64_t)o[u][k] * a.gp] : 0.0f;
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v = o[u][k] >= 0 ? v + g[u][k] * w[u][k] : v;
-        if (live[u]) {
-          if (pb) pb[(int64_t)(run * 64 + src[u]) * a.po_n] = v;
-          if (c[u] >= 0 && v > 0.0f) atomicMax(reinterpret_cast<int*>(tile + c[u] * kC + ch), __float_as_int(v));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < ncell * (kC / 4); i += 1024) {
-    const int cell = i / (kC / 4), q = i % (kC / 4);
-    const int y = y0 + cell / t.tw, x = x0 + cell % t.tw;
-    if (y < a.Ho && x < a.Wo)
-      *reinterpret_cast<float4*>(a.out + (((int64_t)b * a.Ho + y) * a.Wo + x) * a.op + 4 * q) = reinterpret_cast<const float4*>(tile)[i];
-  }
-}
-
 }  // namespace smos
 
 using namespace smos;
@@ -564,33 +440,6 @@ extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, con
   a.gp = grid_pitch; a.op = out_pitch; a.po_b = po_b; a.po_n = po_n;
   a.B = (int)B; a.N = (int)N; a.Kg = Kg; a.Ks = Ks; a.Hg = (int)Hg; a.Wg = (int)Wg; a.Ho = (int)Ho; a.Wo = (int)Wo;
   a.gsy = gscale[0]; a.gsx = gscale[1]; a.ssy = out ? sscale[0] : 0.f; a.ssx = out ? sscale[1] : 0.f;
-  if (out && al16(out) && out_pitch % 4 == 0) {
-    // target staged in LDS tiles (no global atomics; writes every cell, so `out` need not be zero-filled): about one tile
-    // per CU, at most 128 KB each
-    const int64_t cells = Ho * Wo, max_cells = 32768 / C;
-    int64_t want = (B * cells + 255) / 256;
-    want = want < 64 ? 64 : (want > max_cells ? max_cells : want);
-    int64_t tw = Wo <= 256 ? 32 : 128;
-    tw = tw > Wo ? Wo : tw;
-    int64_t th = want / tw;
-    th = th < 1 ? 1 : (th > Ho ? Ho : th);
-    GsTileArgs t;
-    t.g = a;
-    t.th = (int)th; t.tw = (int)tw;
-    t.tiles_y = (int)((Ho + th - 1) / th); t.tiles_x = (int)((Wo + tw - 1) / tw);
-    const size_t lds = (size_t)th * tw * C * sizeof(float);
-    const int64_t blocks = B * t.tiles_y * t.tiles_x;
-    if (lds <= 128 * 1024 && blocks < (1LL << 30)) {
-      KernelSetup ks;
-      const void* fn = C == 32 ? reinterpret_cast<const void*>(&gather_scatter_tiles<32>) : reinterpret_cast<const void*>(&gather_scatter_tiles<64>);
-      if (int rc = kernel_setup(fn, 128 * 1024, 0, &ks, "gather_scatter_cl")) return rc;
-      if (C == 32)
-        hipLaunchKernelGGL((gather_scatter_tiles<32>), dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream, t);
-      else
-        hipLaunchKernelGGL((gather_scatter_tiles<64>), dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream, t);
-      return check_launch("gather_scatter_cl");
-    }
-  }
   const int64_t runs = B * ((N + C - 1) / C);
   const int64_t blocks = (runs * C + kBlock - 1) / kBlock;
   dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));

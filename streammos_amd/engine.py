@@ -405,11 +405,12 @@ class InferenceEngine:
         """B2P gather + P2R scatter, range-view convs, R2P gather + P2B scatter straight into cat_buf[:, c:]
         (multi_view_encoder.py:395-405 / :410-420); everything channels-last, nothing transposed."""
         b = cat_buf.shape[0]
-        # the scatter half stages its target in LDS tiles and writes every cell: no zero fill, no global atomics
-        rv = ops.empty_cl(b, c, rv_hw[0], rv_hw[1], cat_buf.device)
+        rv = ops.empty_cl(b, c, rv_hw[0], rv_hw[1], cat_buf.device, zero=True)
         ops.gather_scatter_cl(cat_buf[:, :c], bev_xy, scale, sphere, scale, out=rv)
         rv = self._stage_cl(rv, rv_blocks)
-        ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=cat_buf[:, c:], pts_out=point_rows)
+        back = cat_buf[:, c:]
+        back.zero_()
+        ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows)
 
     def _stem_sparse_cl(self, bev_cl, pcds_coord):
         """header_bev[0] on the occupied cells of a DENSE channels-last grid (csrc/stem.hip); the engine itself scatters

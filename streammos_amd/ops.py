@@ -824,8 +824,8 @@ def upsample_concat_cl(sources, size):
 
 
 def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None):
-    """grid: channels-last [B,C,Hg,Wg] view; out: channels-last [B,C,Ho,Wo] view (or None) -- every cell is written
-    (LDS-tiled scatter), no zero fill needed; pts_out: [B,N,C] rows (or None)."""
+    """grid: channels-last [B,C,Hg,Wg] view; out: channels-last [B,C,Ho,Wo] view, zero-filled (or None);
+    pts_out: [B,N,C] rows (or None)."""
     _require_cuda("gather_scatter_cl", grid, gcoord, scoord, out, pts_out)
     b, c, hg, wg = grid.shape
     n, kg = gcoord.shape[1], gcoord.shape[2]
