@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
+    ap.add_argument("--label-log", default=None,
+                    help="write the launch-ordered list of kernel labels of one step to this JSON file (used by "
+                         "profiles/pmc_summary.py to tell the conv launches of a rocprofv3 --pmc pass apart; needs --no-pipeline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,6 +308,12 @@ def main():
     single = {k: v for k, v in warm.items() if not k.startswith("stem_")}
     dominant = max(single, key=lambda k: single[k][1]) if single else None
 
+    if args.label_log and rank == 0:
+        with profiling.kernel_timer() as kt_seq:
+            one_step(args.warmup)
+        torch.cuda.synchronize()
+        json.dump(kt_seq.sequence, open(args.label_log, "w"))
+
     sync()
     t0 = time.perf_counter()
     with profiling.kernel_timer(only=dominant) as kt:
@@ -354,6 +363,34 @@ def main():
                              "frac": round(achieved / HBM_PEAK_GBS, 4)}, **common)
             if ctx.get("stem_rows") is not None:
                 roof["stem_rows_per_launch"] = round(ctx["stem_rows"])
+        if roof and dominant.startswith("conv_cl"):
+            # the same launch (same operands) alone on the GPU: in the timed region it shares the chip with the other
+            # pipeline stage's kernels, which stretches its HIP-event time; rocprofv3 --kernel-trace serialises the two
+            # streams, so ITS per-kernel mean (profiles/r02*_kernel_stats.csv) corresponds to this isolated figure
+            profiling.request_replay(dominant)
+            one_step(0)
+            one_step(1)
+            again = profiling.replay_of(dominant)
+            if again is not None:
+                torch.cuda.synchronize()
+                with profiling.kernel_timer(only=dominant) as kt_iso:
+                    for _ in range(30):
+                        again()
+                iso = kt_iso.summary()[dominant][2]
+                roof["in_step_launch_ms"] = roof["avg_launch_ms"]
+                roof["in_step_frac"] = roof["frac"]
+                roof["isolated_launch_ms"] = round(iso, 4)
+                if roof["bound"] == "mfma":
+                    ach = roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12
+                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / FP32_PEAK_TFLOPS, 4)
+                else:
+                    ach = roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9
+                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / HBM_PEAK_GBS, 4)
+                roof["avg_launch_ms"] = round(iso, 4)
+                roof["clock"] = ("HIP events (torch.cuda.Event) on the launch stream around 30 re-runs of the dominant launch with "
+                                 "its own operands, alone on the GPU, right after the timed region (= what rocprofv3 "
+                                 "--kernel-trace reports: the tracer serialises the two pipeline streams); in_step_* = the same "
+                                 "launch inside the timed region, where it shares the CUs with the other stream's kernels")
         if roof and dominant.startswith("point_head") and eng is not None:
             # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
             from streammos_amd import ops as _ops

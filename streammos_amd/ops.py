@@ -474,12 +474,19 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
         raise RuntimeError("conv_cl: residual has shape %s" % (tuple(residual.shape),))
     lib = _lib.load()
     label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, ho, wo, kh, kw, "+res" if residual is not None else "")
+    args = (x.data_ptr(), _cl("conv_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None, _cl("conv_cl", residual) if residual is not None else 0,
+            out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act))
     with torch.cuda.device(x.device), profiling.span(label):
-        rc = lib.smos_conv_cl(x.data_ptr(), _cl("conv_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
-                              residual.data_ptr() if residual is not None else None,
-                              _cl("conv_cl", residual) if residual is not None else 0, out.data_ptr(), _cl("conv_cl", out),
-                              b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act), _stream(x))
+        rc = lib.smos_conv_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_cl")
+    if profiling._replay_label == label:
+        keep = (x, wprep, bias, residual, out)          # the closure keeps the operands alive
+
+        def again(keep=keep):
+            with torch.cuda.device(keep[0].device), profiling.span(label):
+                _lib.check(lib.smos_conv_cl(*args, _stream(keep[0])), "smos_conv_cl")
+        profiling.offer_replay(label, again)
     return out
 
 

@@ -9,12 +9,15 @@ import contextlib
 import torch
 
 _active = None
+_replay_label = None      # label whose next launch is kept (closure over its arguments) for an isolated re-run
+_replay = {}
 
 
 class KernelTimer:
     def __init__(self, only=None):
         self.only = only            # label filter (None = every launch)
         self.events = {}            # label -> list of (start, stop)
+        self.sequence = []          # labels in launch order
 
     @contextlib.contextmanager
     def span(self, label):
@@ -27,6 +30,7 @@ class KernelTimer:
         yield
         b.record()
         self.events.setdefault(label, []).append((a, b))
+        self.sequence.append(label)
 
     def summary(self):
         """label -> (calls, total_ms, mean_ms); synchronises."""
@@ -52,3 +56,21 @@ def span(label):
     if _active is None or torch.cuda.is_current_stream_capturing():
         return contextlib.nullcontext()
     return _active.span(label)
+
+
+def request_replay(label):
+    """Ask ops to keep the next launch carrying `label` (bench.py re-runs the dominant kernel alone on the GPU)."""
+    global _replay_label
+    _replay_label = label
+    _replay.pop(label, None)
+
+
+def offer_replay(label, fn):
+    global _replay_label
+    if label == _replay_label:
+        _replay[label] = fn
+        _replay_label = None
+
+
+def replay_of(label):
+    return _replay.get(label)

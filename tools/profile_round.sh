@@ -1,22 +1,29 @@
 #!/bin/bash
-# Round profile: kernel-trace stats of the default bench + the two PMC passes for the HBM traffic of the point kernels.
-# usage (on the GPU box): bash tools/profile_round.sh <tag>
+# Round profile: kernel-trace stats of the default bench, the two PMC passes for the HBM traffic of the labelled kernels,
+# and the MFMA-busy pass.  usage (on the GPU box): bash tools/profile_round.sh <tag>
+# (--pmc passes carry --kernel-trace only: the pool refuses counter collection combined with other trace domains)
 set -e
-TAG=${1:-r01e}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 > $OUT/bench_trace.log 2>&1
 echo "trace done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 -u $R/bench.py --steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-pipeline > $OUT/bench_fetch.log 2>&1
+PMCARGS="--steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-pipeline"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 -u $R/bench.py $PMCARGS --label-log $OUT/labels.json > $OUT/bench_fetch.log 2>&1
 echo "fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 -u $R/bench.py --steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-pipeline > $OUT/bench_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 -u $R/bench.py $PMCARGS > $OUT/bench_write.log 2>&1
 echo "write done"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- python3 -u $R/bench.py $PMCARGS > $OUT/bench_mfma.log 2>&1
+echo "mfma done"
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
-python3 $R/profiles/pmc_summary.py $F $W > $OUT/pmc_traffic.json
+python3 $R/profiles/pmc_summary.py $F $W $OUT/labels.json > $OUT/pmc_traffic.json
+M=$(find $OUT/mfma -name "*counter_collection.csv" | head -1)
+python3 $R/profiles/mfma_busy_summary.py $M > $OUT/mfma_busy.txt
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 cp $S $OUT/kernel_stats.csv
 python3 $R/profiles/step_breakdown.py $T > $OUT/step_breakdown.txt 2>&1 || true
-rm -rf $OUT/trace $OUT/fetch $OUT/write
+grep "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench_traced.json.log || true
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
 ls -la $OUT
