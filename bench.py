@@ -56,8 +56,9 @@ def algorithmic_bytes(label, ctx=None):
     if name in ("gather_scatter", "gather_scatter_cl"):
         src, n, dst = dims.split("->")
         b, c, h, w = (int(v) for v in src.split("x"))
-        cells = int(np.prod([int(v) for v in dst.split("x")]))
-        return 4 * (b * c * h * w + 4 * b * int(n) + b * c * cells + (b * c * int(n) if cells == 0 else 0))
+        rows = dst.endswith("+pts")                     # the gathered point rows [B, N, C] are an output as well
+        cells = int(np.prod([int(v) for v in dst.replace("+pts", "").split("x")]))
+        return 4 * (b * c * h * w + 4 * b * int(n) + b * c * cells + (b * c * int(n) if cells == 0 or rows else 0))
     if name == "bilinear_gather":
         src, n = dims.split("->")
         b, c, h, w = (int(v) for v in src.split("x"))

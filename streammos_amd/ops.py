@@ -843,7 +843,8 @@ def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, 
     if pts_out is not None:
         po_b, po_n = _rows("gather_scatter_cl", pts_out, c)
     lib = _lib.load()
-    label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d]" % (b, c, hg, wg, n, ho, wo)
+    label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d%s]" % (b, c, hg, wg, n, ho, wo,
+                                                          "+pts" if pts_out is not None and out is not None else "")
     with torch.cuda.device(grid.device), profiling.span(label):
         rc = lib.smos_gather_scatter_cl(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
                                         _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
