@@ -71,6 +71,52 @@ def build_cpu(force=False, verbose=False):
     return CPU_LIB_PATH
 
 
+SHIMS = (("point_deep_cuda_kernel", "SMOS_SHIM_POINT_DEEP"), ("MultiScaleDeformableAttention", "SMOS_SHIM_MSDA"))
+
+
+def shim_path(name):
+    return os.path.join(LIB_DIR, "pybind", name + ".so")
+
+
+def build_pybind_shims(force=False, verbose=False):
+    """g++ build of the two pybind11 modules a reference maintainer would keep (csrc/shim/pybind_shims.cpp, INTEGRATION.md
+    section 3): the reference's function names and argument lists over libsmos_hip.so's C ABI.  Host code only; torch
+    supplies headers and the current HIP stream.  Optional: the shipped Python path binds the C ABI through ctypes."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension
+    build()
+    src = os.path.join(CSRC, "shim", "pybind_shims.cpp")
+    deps = [src, os.path.join(os.path.dirname(PKG), "include", "smos.h")]
+    os.makedirs(os.path.join(LIB_DIR, "pybind"), exist_ok=True)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    out = []
+    procs = []
+    for name, macro in SHIMS:
+        target = shim_path(name)
+        out.append(target)
+        if not (force or _stale(target, deps)):
+            continue
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-deprecated-declarations",
+               "-D" + macro, "-DTORCH_EXTENSION_NAME=" + name, "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+               "-I" + os.path.join(os.path.dirname(PKG), "include"), "-I" + sysconfig.get_paths()["include"]]
+        cmd += ["-I" + p for p in cpp_extension.include_paths("cuda")]
+        cmd += [src, "-o", target, "-L" + torch_lib, "-L" + LIB_DIR, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+                "-ltorch", "-ltorch_python", "-lsmos_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + torch_lib]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for name, p in procs:
+        log, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("pybind shim %s: g++ failed:\n%s" % (name, log.decode()))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="-f" in sys.argv, verbose=True))
     print(build_cpu(force="-f" in sys.argv, verbose=True))
+    if "--shims" in sys.argv:
+        print(build_pybind_shims(force="-f" in sys.argv, verbose=True))

@@ -630,13 +630,27 @@ def test_conv_cl_is_deterministic_and_batch_independent():
     assert torch.equal(a, b) and torch.equal(a[1:2], c)
 
 
+def _binding(kind, name):
+    """The ctypes-backed Python module refapi.install() publishes under the reference's pybind name, or the COMPILED
+    pybind11 twin (csrc/shim/pybind_shims.cpp = INTEGRATION.md section 3, built by __graft_entry__.build())."""
+    if kind == "pybind":
+        from streammos_amd.refapi import compiled
+        return compiled.load(name)
+    if name == "point_deep_cuda_kernel":
+        from streammos_amd.refapi.point_deep import cuda_kernel
+        return cuda_kernel
+    from streammos_amd.refapi import MultiScaleDeformableAttention
+    return MultiScaleDeformableAttention
+
+
+@pytest.mark.parametrize("binding", ["ctypes", "pybind"])
 @pytest.mark.parametrize("name", ["basic", "scaled_neg", "dim3", "relu_like"])
-def test_pybind_name_point_deep_cuda_kernel_with_the_references_argument_lists(golden, name):
+def test_pybind_name_point_deep_cuda_kernel_with_the_references_argument_lists(golden, name, binding):
     """`point_deep.cuda_kernel.voxel_maxpooling_forward / _backward` called exactly as the reference's autograd Function
     calls them (deep_point/__init__.py:25-44, :48-61): caller-allocated zero / -1 filled buffers and the four small META
     TENSORS ON THE DEVICE (int64 sizes / strides / output size, float32 scale).  Bit-exact against the reference's output
-    and gradient."""
-    from streammos_amd.refapi.point_deep import cuda_kernel
+    and gradient, through the Python binding and through the compiled pybind11 module."""
+    cuda_kernel = _binding(binding, "point_deep_cuda_kernel")
     g = golden("ops_voxel_maxpool")
     feat, ind, output_size, scale_rate = cases.voxel_maxpool_cases()[name]
     pcds_feat, pcds_ind = _t(feat).unsqueeze(-1), _t(ind).unsqueeze(-1)
@@ -661,11 +675,13 @@ def test_pybind_name_point_deep_cuda_kernel_with_the_references_argument_lists(g
                                              voxel_out_stride_pt, output_size_pt, scale_rate_pt)
 
 
-def test_pybind_name_msda_module_with_the_references_argument_lists(golden):
+@pytest.mark.parametrize("binding", ["ctypes", "pybind"])
+def test_pybind_name_msda_module_with_the_references_argument_lists(golden, binding):
     """`MultiScaleDeformableAttention.ms_deform_attn_forward / _backward` called as MSDeformAttnFunction calls them
     (deformattn/functions/ms_deform_attn_func.py:21-38): int64 shape / level-start tensors on the device, im2col_step as
-    an int; forward against the reference's golden output, backward against autograd of the torch formulation."""
-    from streammos_amd.refapi import MultiScaleDeformableAttention as MSDA
+    an int; forward against the reference's golden output, backward against autograd of the torch formulation; through
+    the Python binding and through the compiled pybind11 module."""
+    MSDA = _binding(binding, "MultiScaleDeformableAttention")
     from streammos_amd.refapi.deformattn.functions import ms_deform_attn_core_pytorch
     g = golden("ops_msda")
     value, shapes, lsi, loc, attn = cases.msda_cases()["reftest"]

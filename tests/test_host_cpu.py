@@ -81,6 +81,24 @@ def test_pybind_named_shims_keep_the_reference_argument_lists():
     assert np.array_equal(out.numpy(), want) and np.array_equal(idx.numpy(), want_idx)
 
 
+def test_compiled_pybind_shims_load_and_refuse_cpu_tensors():
+    """csrc/shim/pybind_shims.cpp compiles against torch + include/smos.h, links libsmos_hip.so and
+    exports the reference's four function names; without a GPU the only thing to call is the CUDA-tensor check."""
+    from streammos_amd import build
+    from streammos_amd.refapi import compiled
+    build.build_pybind_shims()
+    pd = compiled.load("point_deep_cuda_kernel")
+    ms = compiled.load("MultiScaleDeformableAttention")
+    assert callable(pd.voxel_maxpooling_forward) and callable(pd.voxel_maxpooling_backward)
+    assert callable(ms.ms_deform_attn_forward) and callable(ms.ms_deform_attn_backward)
+    z = torch.zeros(1, 2, 4, 1)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        pd.voxel_maxpooling_forward(z, z, z, z.long(), z.long(), z.long(), z.long(), z)
+    v = torch.zeros(1, 4, 1, 8)
+    with pytest.raises(RuntimeError, match="CPU"):
+        ms.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 4, 1, 1, 1, 2), torch.zeros(1, 4, 1, 1, 1), 1)
+
+
 def test_attnet_state_dict_layout_is_the_reference_layout():
     from streammos_amd.refapi.config import StreamMOS as cfg
     from streammos_amd.refapi.models import StreamMOS
