@@ -11,7 +11,7 @@
 // not depend on it.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
 #include <vector>
@@ -20,6 +20,8 @@
 
 namespace {
 
+// torch-ROCm presents its HIP devices under the device type "cuda": the generic c10::DeviceGuard accepts that, and the HIP
+// stream pool is indexed by the device ordinal either way.
 hipStream_t current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 void check_input(const at::Tensor& t, const char* name) {
@@ -85,7 +87,7 @@ void voxel_maxpooling_forward(at::Tensor pcds_feat, at::Tensor pcds_ind, at::Ten
   TORCH_CHECK(pcds_ind.scalar_type() == pcds_feat.scalar_type() && voxel_out.scalar_type() == pcds_feat.scalar_type(),
               "pcds_feat / pcds_ind / voxel_out dtypes differ");
   Geometry g = geometry(pcds_feat, pcds_ind, voxel_out, scale_rate);
-  c10::hip::HIPGuard guard(pcds_feat.device());
+  c10::DeviceGuard guard(pcds_feat.device());
   at::Tensor flag = at::zeros({4}, pcds_feat.options().dtype(at::kInt));   // "saw a negative feature" scratch
   int rc = smos_voxel_maxpool_fwd(pcds_feat.data_ptr(), g.feat_stride.data(), pcds_ind.data_ptr(), voxel_out.data_ptr(),
                                   g.out_stride.data(), voxel_max_idx.data_ptr<int64_t>(), g.bs, g.c, g.n, g.d,
@@ -110,7 +112,7 @@ void voxel_maxpooling_backward(at::Tensor pcds_feat, at::Tensor pcds_ind, at::Te
   TORCH_CHECK(grad_voxel_out.sizes() == voxel_out.sizes() && grad_pcds_feat.sizes() == pcds_feat.sizes(),
               "gradient shapes must match their tensors");
   Geometry g = geometry(pcds_feat, pcds_ind, voxel_out, scale_rate);
-  c10::hip::HIPGuard guard(pcds_feat.device());
+  c10::DeviceGuard guard(pcds_feat.device());
   int rc = smos_voxel_maxpool_bwd(pcds_feat.data_ptr(), g.feat_stride.data(), pcds_ind.data_ptr(), voxel_out.data_ptr(),
                                   grad_voxel_out.data_ptr(), g.out_stride.data(), grad_pcds_feat.data_ptr(), g.bs, g.c, g.n,
                                   g.d, g.out_size.data(), g.scale.data(), dtype_code(pcds_feat, "voxel_maxpooling_backward"),
@@ -158,7 +160,7 @@ at::Tensor ms_deform_attn_forward(const at::Tensor& value, const at::Tensor& spa
                                   const at::Tensor& level_start_index, const at::Tensor& sampling_loc,
                                   const at::Tensor& attn_weight, const int im2col_step) {
   Dims q = msda_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step);
-  c10::hip::HIPGuard guard(value.device());
+  c10::DeviceGuard guard(value.device());
   at::Tensor out = at::empty({q.n, q.lq, q.m * q.d}, value.options());
   int rc = smos_msda_fwd(value.data_ptr(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
                          sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), q.n, q.s, q.m, q.d, q.l, q.lq, q.p,
@@ -173,7 +175,7 @@ std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor& value, const a
                                                 const int im2col_step) {
   Dims q = msda_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step);
   TORCH_CHECK(grad_output.is_cuda(), "grad_output must be a CUDA tensor");
-  c10::hip::HIPGuard guard(value.device());
+  c10::DeviceGuard guard(value.device());
   at::Tensor go = grad_output.contiguous();
   at::Tensor grad_value = at::zeros_like(value);
   at::Tensor grad_loc = at::zeros_like(sampling_loc);

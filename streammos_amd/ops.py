@@ -4,6 +4,7 @@ torch is used for device memory and streams only: every function launches on
 ``torch.cuda.current_stream`` of the tensors' device and returns without synchronising.
 """
 import ctypes
+import os
 
 import torch
 
@@ -445,13 +446,16 @@ def conv_prepare(w, mt):
     return v.reshape(-1).contiguous()
 
 
+_CONV_MIN_WAVE_TILES = int(os.environ.get("SMOS_CONV_MIN_WAVE_TILES", "2048"))   # tuning knob (tools/ubench_conv.py)
+
+
 def conv_mt(cout, n_pixels, residual=False):
     """Output blocks per wave for smos_conv_cl: wider waves re-use each activation load more often, narrower ones give
     more wave tiles; aim at >= 2 waves for each of the 1024 SIMDs.  With a residual input the kernel holds the residual
     tile in registers, which limits it to mt <= 2."""
     tiles32 = (n_pixels + 31) // 32
     for mt in ((2, 1) if residual else (4, 2, 1)):
-        if cout % (32 * mt) == 0 and tiles32 * (cout // (32 * mt)) >= 2048:
+        if cout % (32 * mt) == 0 and tiles32 * (cout // (32 * mt)) >= _CONV_MIN_WAVE_TILES:
             return mt
     return 1
 

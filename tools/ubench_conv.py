@@ -37,12 +37,15 @@ for name, cin, cout, (kh, kw), stride, (h, w) in LAYERS:
     pad = (kh // 2, kw // 2)
     ho, wo = (h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1
     gf = 2.0 * 4 * ho * wo * cin * cout * kh * kw / 1e9
-    with torch.backends.cudnn.flags(enabled=True, benchmark=True):
-        def lib():
-            y = F.conv2d(x, wcl, None, stride, pad)
-            return ops.bias_act_cl(y, bias, 1, out=y)
-        t_lib = timeit(lib)
-        t_conv = timeit(lambda: F.conv2d(x, wcl, None, stride, pad))
+    if os.environ.get("SMOS_UBENCH_NO_LIB"):      # own kernel only (knob sweeps)
+        t_lib = t_conv = float("nan")
+    else:
+        with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+            def lib():
+                y = F.conv2d(x, wcl, None, stride, pad)
+                return ops.bias_act_cl(y, bias, 1, out=y)
+            t_lib = timeit(lib)
+            t_conv = timeit(lambda: F.conv2d(x, wcl, None, stride, pad))
     res = []
     for mt in (1, 2, 4):
         if cout % (32 * mt):
