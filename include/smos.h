@@ -127,6 +127,12 @@ int smos_vote_clear(uint64_t* table, smos_stream_t stream);
 int smos_vote_accumulate(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels,
                          const double* pose_diff, int32_t recip_quantize, uint64_t* table,
                          smos_stream_t stream);
+/* The same accumulation for a whole voting window in one launch (voxel_voting.py:214-238 loops over the 8 history frames
+ * and the current one): host arrays of `count` device pointers / sizes; pose_diff[f] = 16 host doubles or NULL (identity,
+ * the current frame).  Integer adds commute, so the table equals the one `count` single-frame calls produce. */
+int smos_vote_accumulate_frames(int32_t count, const float* const* pts, const int64_t* n, const int64_t* pt_stride,
+                                const uint8_t* const* labels, const double* const* pose_diff, int32_t recip_quantize,
+                                uint64_t* table, smos_stream_t stream);
 /* out_labels[i] = argmax of the voxel of point i (ties -> lowest class) if the point survives the crop,
  * else labels[i]; lut (device, 256 int32 entries, e.g. {0:0,1:9,2:251}) is applied when non-NULL. */
 int smos_vote_resolve(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels,

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsmos_hip.so")
+LIB_PATH = os.environ.get("SMOS_HIP_LIB") or os.path.join(_PKG, "lib", "libsmos_hip.so")   # override: diagnostic builds
 
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_f32p = ctypes.POINTER(ctypes.c_float)
@@ -27,6 +27,7 @@ SIGNATURES = {
     "smos_tta_argmax": [vp, i64, i64, i64, vp, vp, vp],
     "smos_vote_clear": [vp, vp],
     "smos_vote_accumulate": [vp, i64, i64, vp, c_f64p, i32, vp, vp],
+    "smos_vote_accumulate_frames": [i32, ctypes.POINTER(vp), c_i64p, c_i64p, ctypes.POINTER(vp), ctypes.POINTER(c_f64p), i32, vp, vp],
     "smos_vote_resolve": [vp, i64, i64, vp, i32, vp, vp, vp, vp],
     "smos_dbscan_work_bytes": [i64],
     "smos_dbscan": [vp, i64, i64, ctypes.c_double, i32, vp, vp, i64, i32, vp],

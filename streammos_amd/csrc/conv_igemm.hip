@@ -63,9 +63,18 @@ struct ConvArgs {
 // prefetch once per stage.  Only LDS traffic has to be ordered here: every wave drains its own LDS queue (ring stores
 // landed, fragment reads returned), then the barrier.  The "memory" clobbers keep the compiler from moving ring accesses
 // across it.
+// Diagnostic builds only (tools/ablate_conv.sh): -DSMOS_CONV_ABLATE=<bits> removes one ingredient of the stage at a time
+// (1 barrier, 2 activation requests, 4 weight ring traffic, 8 epilogue stores) to time what is left; results are wrong.
+#ifndef SMOS_CONV_ABLATE
+#define SMOS_CONV_ABLATE 0
+#endif
+#ifndef SMOS_CONV_SCHED
+#define SMOS_CONV_SCHED 1      // 1: eight half groups (shipped); 0: four groups, the cut the in-kernel stamps were written for
+#endif
+
 __device__ __forceinline__ void ring_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!(SMOS_CONV_ABLATE & 1)) __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
@@ -118,7 +127,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
   const int total = iters * a.nstage;
   if (total <= 0) return;
-  for (int i = tid; i < a.cout; i += 256) bias_lds[i] = a.bias ? a.bias[i] : 0.0f;      // published by the prologue's barrier
 
   // Bookkeeping is kept off the per-stage path: the scalar unit is shared by the CU's waves, and a hundred cursor
   // instructions per stage cost more wave time than the stage's 16 MFMAs (in-kernel stamps).  Per stage: three counters and
@@ -144,6 +152,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
+  // The bias is requested here, as the OLDEST load of the kernel, and written to LDS only just before the prologue's barrier:
+  // staged with a plain loop up front, every wave sat through one full memory latency before it issued its first operand
+  // request (two serialised latencies per launch; the small layers run one item per block).  Past Cout the buffer returns 0.
+  const __amdgpu_buffer_rsrc_t bsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout * 4 : 0, 0x00020000);
+  float bias_r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bias_r[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrd, (unsigned)(tid + 256 * k) * 4u, 0, 0));
 
   // ---- activation requests (three stages ahead): position inside the tile = counters + a running element offset ----
   const int xp = (int)a.xp;
@@ -167,6 +183,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + 32u * j, 0, 0);
+      bset[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  unsigned pb_voff = 0x80000000u;
+  auto addr_b = [&]() {
+    const bool ok = pb_valid & ((unsigned)(pb_y0 + pb_dy) < (unsigned)a.H) & ((unsigned)(pb_xs + pb_dx) < (unsigned)a.W);
+    pb_voff = ok ? (unsigned)(pb_base + pb_delta) * 4u : 0x80000000u;
+  };
+  auto load_b_half = [&](float4 (&bset)[4], int j0) {
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, pb_voff + 32u * j, 0, 0);
       bset[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
@@ -232,6 +260,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].w, bv.w, acc[mt], 0, 0, 0);
   };
 
+  auto mfma_half = [&](const float4 (&af)[4][MT], const float4& bv, int i4, bool lo) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4][mt].x : af[i4][mt].z, lo ? bv.x : bv.z, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4][mt].y : af[i4][mt].w, lo ? bv.y : bv.w, acc[mt], 0, 0, 0);
+  };
+
   // ---- the stage being computed: a countdown to the end of its tile; the tile itself is located when it is needed ----
   int c_it = 0, c_left = a.nstage;
   // The residual tile is requested one stage before the stage that ends the tile (a wave-uniform branch; vmcnt retires in
@@ -274,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
         }
         u32x4 ov;
         ov.x = __float_as_uint(o[0]); ov.y = __float_as_uint(o[1]); ov.z = __float_as_uint(o[2]); ov.w = __float_as_uint(o[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff + 4u * (mt * 32 + 8 * g), 0, 0);
+        if (!(SMOS_CONV_ABLATE & 8) || ov.x == 0x7fc12345u)      // ablated: keeps the values alive, stores ~never
+          __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff + 4u * (mt * 32 + 8 * g), 0, 0);
       }
     }
   };
@@ -301,6 +339,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   advance_b();
   if (pb_left == 0) next_tile_b();
   if (RES && c_left == 1) request_residual();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (256 * k < a.cout) bias_lds[tid + 256 * k] = bias_r[k];      // Cout <= 1024; rounded up to whole 256s in the LDS size
   ring_barrier();
   read_a(af, 0, 0);
   read_a(af, 0, 1);
@@ -312,22 +353,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   //   G2 | step the request position; barrier (publishes slice g + 1); fragments i4 = 0, 1 of the next stage
   //   G3 | rare branches: end of a tile (epilogue), residual request for a tile about to end, next tile of the requests
   // Slot sn = (g + 1) % 4 was last read in stage g - 3.
+#if SMOS_CONV_SCHED == 1
+// Finer cut: eight half groups of 2 * MT MFMAs, one small piece of the stage's non-matrix work after each.  A piece only
+// overlaps with the matrix pipe while the MFMA issued just before it is executing (64 cycles), so the pieces are kept to a
+// handful of instructions each.
+#define SMOS_STAGE(bc, bp, sc, sn, n0, n1, n2, n3) \
+  do {                                             \
+    mfma_half(af, bc[0], 0, true);                 \
+    SMOS_FENCE();                                  \
+    park(sn, n0, n1, n2, n3);                      \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[0], 0, false);                \
+    SMOS_FENCE();                                  \
+    load_a(n0, n1, n2, n3);                        \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[1], 1, true);                 \
+    SMOS_FENCE();                                  \
+    read_a(af, sc, 2);                             \
+    read_a(af, sc, 3);                             \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[1], 1, false);                \
+    SMOS_FENCE();                                  \
+    addr_b();                                      \
+    load_b_half(bp, 0);                            \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[2], 2, true);                 \
+    SMOS_FENCE();                                  \
+    load_b_half(bp, 2);                            \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[2], 2, false);                \
+    SMOS_FENCE();                                  \
+    advance_b();                                   \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[3], 3, true);                 \
+    SMOS_FENCE();                                  \
+    ring_barrier();                                \
+    read_a(af, sn, 0);                             \
+    read_a(af, sn, 1);                             \
+    SMOS_FENCE();                                  \
+    mfma_half(af, bc[3], 3, false);                \
+    SMOS_FENCE();                                  \
+    if (--c_left == 0) {                           \
+      epilogue();                                  \
+      c_left = a.nstage;                           \
+      ++c_it;                                      \
+    }                                              \
+    if (RES && c_left == 1) request_residual();    \
+    if (pb_left == 0) next_tile_b();               \
+  } while (0)
+#else
 #define SMOS_STAGE(bc, bp, sc, sn, n0, n1, n2, n3) \
   do {                                             \
     SMOS_STAMP(8);                                 \
     mfma_group(af, bc[0], 0);                      \
     SMOS_FENCE();                                  \
     SMOS_STAMP(0);                                 \
-    park(sn, n0, n1, n2, n3);                      \
-    load_a(n0, n1, n2, n3);                        \
-    read_a(af, sc, 2);                             \
-    read_a(af, sc, 3);                             \
+    if (!(SMOS_CONV_ABLATE & 4)) {                 \
+      park(sn, n0, n1, n2, n3);                    \
+      load_a(n0, n1, n2, n3);                      \
+      read_a(af, sc, 2);                           \
+      read_a(af, sc, 3);                           \
+    }                                              \
     SMOS_FENCE();                                  \
     SMOS_STAMP(1);                                 \
     mfma_group(af, bc[1], 1);                      \
     SMOS_FENCE();                                  \
     SMOS_STAMP(2);                                 \
-    load_b(bp);                                    \
+    if (!(SMOS_CONV_ABLATE & 2)) load_b(bp);       \
     SMOS_FENCE();                                  \
     SMOS_STAMP(3);                                 \
     mfma_group(af, bc[2], 2);                      \
@@ -335,8 +427,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     SMOS_STAMP(4);                                 \
     advance_b();                                   \
     ring_barrier();                                \
-    read_a(af, sn, 0);                             \
-    read_a(af, sn, 1);                             \
+    if (!(SMOS_CONV_ABLATE & 4)) {                 \
+      read_a(af, sn, 0);                           \
+      read_a(af, sn, 1);                           \
+    }                                              \
     SMOS_FENCE();                                  \
     SMOS_STAMP(5);                                 \
     mfma_group(af, bc[3], 3);                      \
@@ -352,16 +446,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     SMOS_STAMP(7);                                 \
   } while (0)
 
+#endif
+
 #ifdef SMOS_CONV_STAMPS
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
   const unsigned long long clk0 = stamp_last, real0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  // Four stages per trip (the register sets and ring slots rotate with period 4); the loop runs whole trips only and the
+  // last 0..3 stages follow as straight-line code.  hipcc's wait-count pass honours every path of the control-flow graph:
+  // with guarded stages inside the loop ("if (g + 1 < total) stage 2; if (g + 2 < total) stage 3; ...") there are paths on
+  // which a stage is skipped and a later one runs, and with a break in the middle the structurizer's exit block falls
+  // through to the loop header -- on such paths the register set a stage consumes was requested only one stage earlier, so
+  // the pass emitted vmcnt(3) instead of vmcnt(13) at the head of two of the four stages and the three-stage prefetch
+  // collapsed to less than one (found by reading the ISA; the stage heads must read vmcnt(13) / (15) / (19) for MT 1 / 2 / 4).
+  int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < total; g += 4) {
+  for (; g + 4 <= total; g += 4) {
     SMOS_STAGE(b0, b3, 0, 1, ao0, ao1, ao2, ao3);
-    if (g + 1 < total) SMOS_STAGE(b1, b0, 1, 2, ae0, ae1, ae2, ae3);
-    if (g + 2 < total) SMOS_STAGE(b2, b1, 2, 3, ao0, ao1, ao2, ao3);
-    if (g + 3 < total) SMOS_STAGE(b3, b2, 3, 0, ae0, ae1, ae2, ae3);
+    SMOS_STAGE(b1, b0, 1, 2, ae0, ae1, ae2, ae3);
+    SMOS_STAGE(b2, b1, 2, 3, ao0, ao1, ao2, ao3);
+    SMOS_STAGE(b3, b2, 3, 0, ae0, ae1, ae2, ae3);
+  }
+  if (g < total) {
+    SMOS_STAGE(b0, b3, 0, 1, ao0, ao1, ao2, ao3);
+    if (g + 1 < total) {
+      SMOS_STAGE(b1, b0, 1, 2, ae0, ae1, ae2, ae3);
+      if (g + 2 < total) SMOS_STAGE(b2, b1, 2, 3, ao0, ao1, ao2, ao3);
+    }
   }
 #ifdef SMOS_CONV_STAMPS
   if (a.stamps && lane == 0) {
@@ -379,7 +490,7 @@ using namespace smos;
 
 template <int MT, bool RES>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 3) / 4 * 4) * sizeof(float);
+  const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float);
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES>), 4 * 256 * MT * sizeof(float4) + 4096, 256, &ks, "conv_cl"))
     return rc;

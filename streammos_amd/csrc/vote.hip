@@ -78,6 +78,34 @@ __global__ __launch_bounds__(kBlock) void vote_accumulate(const float* __restric
   }
 }
 
+// The whole voting window in one launch: blockIdx.y = frame.  Nine launches of ~7 us each (launch-bound at 120 k points)
+// become one; the table update is a commutative integer add, so the result does not depend on how frames are grouped.
+constexpr int kMaxFrames = 12;
+struct FrameSet {
+  const float* pts[kMaxFrames];
+  const uint8_t* labels[kMaxFrames];
+  int64_t n[kMaxFrames];
+  int64_t stride[kMaxFrames];
+  Pose pose[kMaxFrames];
+};
+
+__global__ __launch_bounds__(kBlock) void vote_accumulate_frames(FrameSet fs, Quant q, unsigned long long* __restrict__ table) {
+  const int f = blockIdx.y;
+  const float* __restrict__ pts = fs.pts[f];
+  const uint8_t* __restrict__ labels = fs.labels[f];
+  const int64_t n = fs.n[f], stride = fs.stride[f];
+  const Pose& pose = fs.pose[f];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float x, y, z;
+    load_xyz(pts + i * stride, pose, x, y, z);
+    const int64_t v = voxel_of(x, y, z, q);
+    if (v < 0) continue;
+    const unsigned lab = labels[i];
+    if (lab > 2) continue;
+    atomicAdd(table + v, 1ULL << (21 * lab));
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void vote_resolve(const float* __restrict__ pts, int64_t n, int64_t stride,
                                                        const uint8_t* __restrict__ labels, Quant q,
                                                        const unsigned long long* __restrict__ table,
@@ -182,6 +210,42 @@ extern "C" int smos_vote_accumulate(const float* pts, int64_t n, int64_t pt_stri
   hipLaunchKernelGGL(vote_accumulate, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, pts, n, pt_stride, labels,
                      p, make_quant(recip_quantize), (unsigned long long*)table);
   return check_launch("vote_accumulate");
+}
+
+extern "C" int smos_vote_accumulate_frames(int32_t count, const float* const* pts, const int64_t* n, const int64_t* pt_stride,
+                                           const uint8_t* const* labels, const double* const* pose_diff,
+                                           int32_t recip_quantize, uint64_t* table, smos_stream_t stream) {
+  SMOS_REQUIRE(count >= 0 && (count == 0 || (pts && n && pt_stride && labels && pose_diff)), "vote_accumulate_frames: null array");
+  int64_t total = 0;
+  for (int f = 0; f < count; ++f) {
+    SMOS_REQUIRE(n[f] >= 0 && pt_stride[f] >= 3, "vote_accumulate_frames: bad sizes in frame %d (n=%lld stride=%lld)", f,
+                 (long long)n[f], (long long)pt_stride[f]);
+    SMOS_REQUIRE(n[f] == 0 || (pts[f] && labels[f]), "vote_accumulate_frames: null device pointer in frame %d", f);
+    total += n[f];
+  }
+  SMOS_REQUIRE(total < (1LL << 21), "vote_accumulate_frames: %lld points overflow a 21-bit vote counter", (long long)total);
+  SMOS_REQUIRE(total == 0 || table, "vote_accumulate_frames: null table");
+  for (int f = 0; f < count;) {
+    FrameSet fs;
+    int m = 0;
+    int64_t longest = 0;
+    for (; f < count && m < kMaxFrames; ++f) {
+      if (n[f] == 0) continue;
+      fs.pts[m] = pts[f];
+      fs.labels[m] = labels[f];
+      fs.n[m] = n[f];
+      fs.stride[m] = pt_stride[f];
+      fs.pose[m].identity = pose_diff[f] ? 0 : 1;
+      for (int i = 0; i < 12; ++i) fs.pose[m].m[i] = pose_diff[f] ? pose_diff[f][i] : 0.0;
+      longest = n[f] > longest ? n[f] : longest;
+      ++m;
+    }
+    if (m == 0) continue;
+    hipLaunchKernelGGL(vote_accumulate_frames, dim3(grid_for(longest), m), dim3(kBlock), 0, (hipStream_t)stream, fs,
+                       make_quant(recip_quantize), (unsigned long long*)table);
+    if (int rc = check_launch("vote_accumulate_frames")) return rc;
+  }
+  return SMOS_OK;
 }
 
 extern "C" int smos_vote_resolve(const float* pts, int64_t n, int64_t pt_stride, const uint8_t* labels,

@@ -210,6 +210,34 @@ def vote_accumulate(points, labels, table, pose_diff=None, recip_quantize=False)
     _lib.check(rc, "smos_vote_accumulate")
 
 
+def vote_accumulate_frames(frames, table, recip_quantize=False):
+    """The whole voting window in one launch.  frames: list of (points [n, >=3] float32 rows, labels [n] uint8, pose_diff
+    4x4 numpy float64 or None for the current frame)."""
+    if not frames:
+        return
+    count = len(frames)
+    pts, lab = (ctypes.c_void_p * count)(), (ctypes.c_void_p * count)()
+    n, stride = (ctypes.c_int64 * count)(), (ctypes.c_int64 * count)()
+    pose = (_lib.c_f64p * count)()
+    keep = []
+    for f, (points, labels, pose_diff) in enumerate(frames):
+        _require_cuda("vote_accumulate_frames", points, labels, table)
+        if points.dtype != torch.float32 or labels.dtype != torch.uint8 or points.stride(1) != 1 or points.device != table.device:
+            raise RuntimeError("vote_accumulate_frames: points must be float32 rows and labels uint8, on the table's device")
+        if labels.shape[0] != points.shape[0] or not labels.is_contiguous():
+            raise RuntimeError("vote_accumulate_frames: one contiguous label per point")
+        pts[f], lab[f], n[f], stride[f] = points.data_ptr(), labels.data_ptr(), points.shape[0], points.stride(0)
+        if pose_diff is not None:
+            arr = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
+            keep.append(arr)
+            pose[f] = ctypes.cast(arr, _lib.c_f64p)
+    lib = _lib.load()
+    with torch.cuda.device(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
+        rc = lib.smos_vote_accumulate_frames(count, pts, n, stride, lab, pose, 1 if recip_quantize else 0, table.data_ptr(),
+                                             torch.cuda.current_stream(table.device).cuda_stream)
+    _lib.check(rc, "smos_vote_accumulate_frames")
+
+
 def vote_resolve(points, labels, table, lut=None, recip_quantize=False):
     _require_cuda("vote_resolve", points, labels, table, lut)
     out = torch.empty(points.shape[0], dtype=torch.int32, device=points.device)

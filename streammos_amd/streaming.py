@@ -67,12 +67,14 @@ class VoxelVoter:
         pts, pred, pose = self.frames[fid]
         inv_cur = np.linalg.inv(pose)
         ops.vote_clear(self.table)
+        window = []
         for h in vote_history_ids(fid, self.window):
             if h not in self.frames:
                 continue
             hp, hl, hpose = self.frames[h]
-            ops.vote_accumulate(hp, hl, self.table, pose_diff=inv_cur.dot(hpose), recip_quantize=self.recip)
-        ops.vote_accumulate(pts, pred, self.table, recip_quantize=self.recip)
+            window.append((hp, hl, inv_cur.dot(hpose)))
+        window.append((pts, pred, None))
+        ops.vote_accumulate_frames(window, self.table, recip_quantize=self.recip)     # one launch for the whole window
         return ops.vote_resolve(pts, pred, self.table, lut=self.lut, recip_quantize=self.recip)
 
     def push(self, points, preds, pose):
@@ -158,9 +160,8 @@ class InstanceVoter(VoxelVoter):
         inv_cur = np.linalg.inv(pose)
         history = [(h, inv_cur.dot(self.frames[h][2])) for h in vote_history_ids(fid, self.window) if h in self.frames]
         ops.vote_clear(self.table)
-        for h, diff in history:
-            ops.vote_accumulate(self.frames[h][0], self.frames[h][1], self.table, pose_diff=diff, recip_quantize=self.recip)
-        ops.vote_accumulate(pts, pred, self.table, recip_quantize=self.recip)
+        ops.vote_accumulate_frames([(self.frames[h][0], self.frames[h][1], diff) for h, diff in history] + [(pts, pred, None)],
+                                   self.table, recip_quantize=self.recip)
         labels = ops.vote_resolve(pts, pred, self.table, lut=None, recip_quantize=self.recip)
         fg = torch.nonzero(self.bf[fid] == 2).flatten()                   # :145
         if fg.numel() > 0:

@@ -440,6 +440,22 @@ def test_vote_full_size_local_map_bit_exact():
     # could only show after the rounding to float32 with probability ~1e-9 per coordinate (measured: 0 of 1.44 M
     # pose-aligned coordinates, 0 of 120 000 refined labels differ; tools/diag_bitexact.py).
     assert np.array_equal(got, want), int((got != want).sum())
+    # the one-launch form of the same window (what the streaming runner issues): identical table, word for word;
+    # 14 frames exercise the split into launches of at most 12, an empty frame in the middle is skipped
+    window = [(_t(scans[k]), _t(preds[k]), inv_cur.dot(poses[k])) for k in range(cur_id - 1, cur_id - 9, -1)]
+    window.append((_t(scans[cur_id]), _t(preds[cur_id]), None))
+    batched = torch.empty_like(table)
+    ops.vote_clear(batched)
+    ops.vote_accumulate_frames(window, batched)
+    assert torch.equal(batched, table)
+    empty = (torch.zeros((0, 4), device=DEV), torch.zeros(0, dtype=torch.uint8, device=DEV), None)
+    small = [(w[0][:9000], w[1][:9000], w[2]) for w in (window + window[:5])]
+    ops.vote_clear(batched)
+    ops.vote_accumulate_frames(small[:7] + [empty] + small[7:], batched)
+    ops.vote_clear(table)
+    for p, l, d in small:
+        ops.vote_accumulate(p, l, table, pose_diff=d)
+    assert torch.equal(batched, table) and int(table.sum().item()) > 0
 
 
 def test_zero_sized_inputs_are_no_ops():

@@ -11,7 +11,7 @@ diag = "/tmp/libsmos_stamps.so"
 objs = []
 for src in build.sources():
     obj = "/tmp/stamps_" + os.path.basename(src)[:-4] + ".o"
-    subprocess.check_call([build.HIPCC] + build.FLAGS + ["-DSMOS_CONV_STAMPS", "-c", src, "-o", obj])
+    subprocess.check_call([build.HIPCC] + build.FLAGS + ["-DSMOS_CONV_STAMPS", "-DSMOS_CONV_SCHED=0", "-c", src, "-o", obj])
     objs.append(obj)
 subprocess.check_call([build.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", diag] + objs)
 _lib.LIB_PATH = diag
