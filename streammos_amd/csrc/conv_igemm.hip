@@ -28,6 +28,7 @@
 //   epilogue   = out = act(acc + bias [+ residual]) from the accumulators, 16-byte stores (lane (p, h), register r <->
 //                channel 32 mt + 8 (r >> 2) + 4 h + (r & 3)); inputs, residual and output may be channel slices of
 //                wider channels-last buffers (row pitches).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "smos_common.h"
@@ -157,9 +158,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   // request (two serialised latencies per launch; the small layers run one item per block).  Past Cout the buffer returns 0.
   const __amdgpu_buffer_rsrc_t bsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout * 4 : 0, 0x00020000);
-  float bias_r[4];
+  float bias_r[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) bias_r[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrd, (unsigned)(tid + 256 * k) * 4u, 0, 0));
+  for (int k = 0; k < 8; ++k) bias_r[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrd, (unsigned)(tid + 256 * k) * 4u, 0, 0));
 
   // ---- activation requests (three stages ahead): position inside the tile = counters + a running element offset ----
   const int xp = (int)a.xp;
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   if (pb_left == 0) next_tile_b();
   if (RES && c_left == 1) request_residual();
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (256 * k < a.cout) bias_lds[tid + 256 * k] = bias_r[k];      // Cout <= 1024; rounded up to whole 256s in the LDS size
+  for (int k = 0; k < 8; ++k)
+    if (256 * k < a.cout) bias_lds[tid + 256 * k] = bias_r[k];      // Cout <= 2048; rounded up to whole 256s in the LDS size
   ring_barrier();
   read_a(af, 0, 0);
   read_a(af, 0, 1);
@@ -488,18 +489,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
 
 using namespace smos;
 
+static const int kDefaultBlocksPerCu[3] = {2, 2, 2};      // MT = 1, 2, 4
+
 template <int MT, bool RES>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float);
   KernelSetup ks;
-  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES>), 4 * 256 * MT * sizeof(float4) + 4096, 256, &ks, "conv_cl"))
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES>), 4 * 256 * MT * sizeof(float4) + 8192, 256, &ks, "conv_cl"))
     return rc;
-  static const int want_per_cu = [] {                       // tuning knob (tools/ubench_conv.py); default below
-    const char* e = getenv("SMOS_CONV_BLOCKS_PER_CU");
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 8 ? v : 2;
+  // Resident blocks per CU.  Alone on the GPU two are best (tools/ubench_conv.py); inside the two-stream step the other
+  // stream's kernels need room on the CU to run beside a convolution at all.  SMOS_CONV_BLOCKS_PER_CU = "n" or "n1,n2,n4"
+  // (per MT) overrides the default for tuning.
+  static const int want_per_cu = [] {
+    int v[3] = {kDefaultBlocksPerCu[0], kDefaultBlocksPerCu[1], kDefaultBlocksPerCu[2]};
+    if (const char* e = getenv("SMOS_CONV_BLOCKS_PER_CU")) {
+      int a = 0, b = 0, c = 0;
+      const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);
+      if (n == 1 && a >= 1 && a <= 8) v[0] = v[1] = v[2] = a;
+      if (n == 3 && a >= 1 && a <= 8 && b >= 1 && b <= 8 && c >= 1 && c <= 8) v[0] = a, v[1] = b, v[2] = c;
+    }
+    return v[MT == 1 ? 0 : MT == 2 ? 1 : 2];
   }();
-  const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;   // default two blocks per CU = 2 waves per SIMD
+  const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_igemm<MT, RES>), dim3(grid), dim3(256), lds, s, a);
@@ -518,7 +529,7 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
   SMOS_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && (stride == 1 || stride == 2) && pad_h >= 0 && pad_w >= 0 &&
                    act >= 0 && act <= 2, "conv_cl: kernel up to 7 x 7, stride 1 or 2");
   const int64_t Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
-  SMOS_REQUIRE(Ho > 0 && Wo > 0 && Cout <= 1024, "conv_cl: empty output / more than 1024 output channels");
+  SMOS_REQUIRE(Ho > 0 && Wo > 0 && Cout <= 2048, "conv_cl: empty output / more than 2048 output channels");
   SMOS_REQUIRE(x && wprep && out && x_pitch >= Cin && out_pitch >= Cout && x_pitch % 4 == 0 && out_pitch % 4 == 0 &&
                    (!res || (res_pitch >= Cout && res_pitch % 4 == 0)), "conv_cl: null pointer / bad pitch");
   SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |

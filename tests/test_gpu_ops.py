@@ -597,6 +597,7 @@ _CONV_CASES = [
     (32, 32, (3, 3), 1, (13, 45), 1, 2, True),          # partial tiles in both directions
     (64, 64, (3, 3), 2, (27, 51), 2, 1, False),         # odd input under stride 2
     (32, 64, (3, 3), 1, (3, 8), 1, 1, False),           # smaller than one tile
+    (128, 1152, (1, 1), 1, (8, 32), 4, 0, False),       # the decoder's nine tap products as one 1x1 convolution (Cout > 1024)
 ]
 
 
