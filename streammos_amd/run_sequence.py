@@ -80,7 +80,12 @@ def run_sequence(model, seq_dir, out_dir, device="cuda:0", vote=True, frame_poin
     for i in range(len(files)):
         idx = [min(j, len(files) - 1) for j in preprocess.window_indices(i, len(files), seq_num)]
         if device_preprocess:
-            out = runner.step_raw([dev_scan(j) for j in idx], [poses[j] for j in idx], frame_point_num)
+            nxt = None
+            if i + 1 < len(files):
+                nxt = [min(j, len(files) - 1) for j in preprocess.window_indices(i + 1, len(files), seq_num)]
+            out = runner.step_raw([dev_scan(j) for j in idx], [poses[j] for j in idx], frame_point_num,
+                                  next_scans=[dev_scan(j) for j in nxt] if nxt else None,
+                                  next_poses=[poses[j] for j in nxt] if nxt else None)
         else:
             sample = preprocess.build_sample([scan(j) for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
             out = runner.step(runner.upload(sample, scan(i)), poses[i])

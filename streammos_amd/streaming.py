@@ -313,6 +313,8 @@ class StreamRunner:
         self.memory = None
         self.frame = 0
         self._pre_enc = None
+        self._raw_ahead = None
+        self.__dict__.pop("_raw_cache", None)
         if self.voter is not None:
             self.voter.reset()
 
@@ -341,22 +343,78 @@ class StreamRunner:
         return dev
 
     @torch.no_grad()
-    def step_raw(self, scans, poses, frame_point_num=160000):
-        """One scan from RAW data: scans = list of T host (numpy) or device [n,4] float32 scans, current first;
-        poses = their 4x4 poses.  Preprocessing runs on the device (streammos_amd.device_preprocess, row f1):
-        only the raw scans cross PCIe and nothing synchronises with the host."""
-        from .device_preprocess import DevicePreprocessor
-        if getattr(self, "_pre", None) is None or self._pre.N != frame_point_num:
-            self._pre = DevicePreprocessor(self.device, frame_point_num=frame_point_num)
-        dev_scans = [s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s)) for s in scans]
-        dev_scans = [s.to(self.device, non_blocking=True) for s in dev_scans]
+    def _upload_raw(self, scan):
+        """Host scan -> device, once per scan object (a window re-uses the scans of the previous frames), through a small
+        ring of pinned staging buffers: a copy from pageable memory would hold the host until the stream has drained, and
+        pinning per call costs milliseconds."""
+        cache = self.__dict__.setdefault("_raw_cache", collections.OrderedDict())
+        hit = cache.get(id(scan))
+        if hit is not None and hit[0] is scan:
+            return hit[1]
+        host = scan if torch.is_tensor(scan) else torch.from_numpy(np.ascontiguousarray(scan, dtype=np.float32))
+        if host.is_cuda:
+            return host
+        if not host.is_pinned():
+            ring = self.__dict__.setdefault("_raw_ring", {"slots": [], "next": 0})
+            if len(ring["slots"]) < 8:
+                ring["slots"].append([torch.empty(max(host.numel(), 4 * 160000), dtype=torch.float32).pin_memory(), None])
+                slot = ring["slots"][-1]
+            else:
+                slot = ring["slots"][ring["next"] % 8]
+                ring["next"] += 1
+            if slot[1] is not None:
+                slot[1].synchronize()                       # the copy that last used this buffer (8 uploads ago)
+            if slot[0].numel() < host.numel():
+                slot[0] = torch.empty(host.numel(), dtype=torch.float32).pin_memory()
+            staged = slot[0][:host.numel()].view(host.shape)
+            staged.copy_(host)
+            dev = staged.to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.device))
+        else:
+            dev = host.to(self.device, non_blocking=True)
+        cache[id(scan)] = (scan, dev)
+        while len(cache) > 16:
+            cache.popitem(last=False)
+        return dev
+
+    def _build_raw(self, scans, poses):
+        """H2D of the raw scans not yet on the device + device preprocessing, on the CURRENT stream."""
+        dev_scans = [self._upload_raw(s) for s in scans]
         inv_cur = np.linalg.inv(np.asarray(poses[0], dtype=np.float64))
         # the current scan also goes through inv(P_cur) * P_cur, which is the identity only up to rounding
         # (the reference does exactly that, datasets/data_StreamMOS.py:424-467)
         built = self._pre.build(dev_scans, [inv_cur.dot(np.asarray(p, dtype=np.float64)) for p in poses])
         built["raw_scan"] = dev_scans[0]
+        return built
+
+    def step_raw(self, scans, poses, frame_point_num=160000, next_scans=None, next_poses=None):
+        """One scan from RAW data: scans = list of T host (numpy) or device [n,4] float32 scans, current first;
+        poses = their 4x4 poses.  Preprocessing runs on the device (streammos_amd.device_preprocess, row f1):
+        only the raw scans cross PCIe and nothing synchronises with the host.  next_scans / next_poses: the following
+        frame's window (pipeline mode): its upload, preprocessing and encoder run on the side stream beside this frame's
+        decoder, and the next call (whose ``scans[0]`` must be the same object as this ``next_scans[0]``) picks them up."""
+        from .device_preprocess import DevicePreprocessor
+        if getattr(self, "_pre", None) is None or self._pre.N != frame_point_num:
+            self._pre = DevicePreprocessor(self.device, frame_point_num=frame_point_num)
+            self._raw_ahead = None
+        ahead, self._raw_ahead = getattr(self, "_raw_ahead", None), None
+        built = ahead[1] if ahead is not None and ahead[0] is scans[0] else self._build_raw(scans, poses)
+        nxt = None
+        if next_scans is not None and self.pipeline and not self.use_graph:
+            main = torch.cuda.current_stream(self.device)
+            if any(torch.is_tensor(t) and t.is_cuda for t in next_scans):
+                self._side.wait_stream(main)            # device-resident scans: produced by whatever main has queued so far
+            with torch.cuda.stream(self._side):
+                nxt = self._build_raw(next_scans, next_poses)
+                nxt["ready"] = torch.cuda.Event()
+                nxt["ready"].record(self._side)
+            for t in nxt.values():                      # allocated on the side stream, consumed on the main one later
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+            self._raw_ahead = (next_scans[0], nxt)
         self._last_built = built        # run_sequence checks its in_range_counts when it reads the labels back
-        return self.step(built, poses[0])
+        return self.step(built, poses[0], next_dev=nxt)
 
     def check_last_raw_sample(self):
         """The device preprocessing drops points beyond frame_point_num instead of raising (no sync on the hot path);

@@ -70,3 +70,32 @@ def test_step_raw_equals_host_preprocessed_step():
         assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
         for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
             assert (la == lb).float().mean().item() >= 0.999
+
+
+def test_step_raw_with_look_ahead_equals_plain_step_raw():
+    """step_raw(next_scans=...) uploads, preprocesses and encodes the following frame on the side stream beside the current
+    frame's decoder; labels, logits and voted frames must be those of the serial raw path, bit for bit (host arrays and
+    device-resident scans; the last frame has no successor)."""
+    from streammos_amd import streaming
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(7)]
+    poses = [synth.synthetic_pose(k) for k in range(7)]
+    for on_device in (False, True):
+        src = [torch.from_numpy(s).to(DEV) for s in scans] if on_device else scans
+        plain = streaming.StreamRunner(model, DEV, vote=True)
+        ahead = streaming.StreamRunner(model, DEV, vote=True, pipeline=True)
+        plain.voter.window = ahead.voter.window = 3
+        for i in range(6):
+            idx = preprocess.window_indices(i, 7, 3)
+            nxt = preprocess.window_indices(i + 1, 7, 3) if i < 5 else None
+            oa = plain.step_raw([src[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048)
+            ob = ahead.step_raw([src[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048,
+                                next_scans=[src[j] for j in nxt] if nxt else None,
+                                next_poses=[poses[j] for j in nxt] if nxt else None)
+            assert torch.equal(oa["pred_cls"], ob["pred_cls"]) and torch.equal(oa["raw_labels"], ob["raw_labels"])
+            assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
+            for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
+                assert torch.equal(la, lb)
