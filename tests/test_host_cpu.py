@@ -146,6 +146,28 @@ def test_refapi_install_publishes_reference_names():
     assert out.stdout.split()[0] == "474"
 
 
+def test_refapi_runs_an_unchanged_entry_script(tmp_path):
+    """python -m streammos_amd.refapi <script> [args]: the script sees the reference's import names, its own argv and its
+    own directory on sys.path -- the way val_StreamMOS.py starts (`from models import *`, eval of the config's prefix)."""
+    (tmp_path / "helper_next_to_script.py").write_text("VALUE = 7\n")
+    script = tmp_path / "val_like.py"
+    script.write_text(
+        "import sys, argparse\n"
+        "import deep_point\n"
+        "from models import *\n"
+        "import helper_next_to_script\n"
+        "import importlib\n"
+        "ap = argparse.ArgumentParser(); ap.add_argument('--config'); a = ap.parse_args()\n"
+        "cfg = importlib.import_module(a.config.replace('.py', '').replace('/', '.'))\n"
+        "g, d, m, o = cfg.get_config()\n"
+        "model = eval(m.prefix)(m)\n"
+        "print(__name__, len(model.state_dict()), helper_next_to_script.VALUE, sys.argv[1:])\n")
+    out = subprocess.run([sys.executable, "-m", "streammos_amd.refapi", str(script), "--config", "config/StreamMOS.py"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[:3] == ["__main__", "474", "7"] and "--config" in out.stdout
+
+
 def test_vote_history_window_follows_the_reference():
     assert streaming.vote_history_ids(8) == [7, 6, 5, 4, 3, 2, 1, 0]       # voxel_voting.py:182
     assert streaming.vote_history_ids(20) == list(range(19, 11, -1))
