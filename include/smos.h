@@ -255,10 +255,16 @@ int smos_add_layer_norm(const float* x, const float* res, const float* gamma, co
  * blocks per wave (a tuning knob), KH, KW <= 7, stride 1 or 2.  bias / res may be NULL.
  * wprep: Cout * Cin * KH * KW floats in MFMA operand order for the chosen mt; with stage = (ky * KW + kx) * (Cin / 32) + cc:
  *   wprep[((((ct * n_stage + stage) * 4 + i4) * mt + m) * 64 + lane) * 4 + c]
- *       = w[ct * 32 * mt + m * 32 + (lane & 31)][cc * 32 + 8 * i4 + 4 * (lane >> 5) + c][ky][kx]. */
+ *       = w[ct * 32 * mt + m * 32 + (lane & 31)][cc * 32 + 8 * i4 + 4 * (lane >> 5) + c][ky][kx].
+ * chan_sums (may be NULL; needs res == NULL): [B][chunks][Cout] with chunks = smos_conv_cl_sum_chunks(Ho, Wo); entry
+ *   (b, chunk, c) = sum of out[b, y, x, c] over one output row segment of 32 pixels (chunk = ((y / 4) * ceil(Wo / 32) +
+ *   x / 32) * 4 + y % 4; segments outside the image hold 0): the global-average-pool input of a ChannelAtt block
+ *   (networks/backbone.py:57-73) without another pass over the map.  Summation order is fixed (run-to-run identical). */
+int64_t smos_conv_cl_sum_chunks(int64_t Ho, int64_t Wo);
 int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
                  float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t KH,
-                 int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt, int32_t act, smos_stream_t stream);
+                 int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt, int32_t act, float* chan_sums,
+                 smos_stream_t stream);
 
 /* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
  * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels
@@ -349,6 +355,12 @@ int smos_channel_gate_residual_cl(const float* y, int64_t y_pitch, const float* 
                                   const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
                                   int64_t out_pitch, float* ws, int64_t ws_floats, int64_t B, int64_t C, int64_t Cr, int64_t HW,
                                   smos_stream_t stream);
+/* The same block fed by the channel sums a smos_conv_cl launch left behind (chan_sums [B][chunks][C], see smos_conv_cl):
+ * gate MLP + out = relu((y + bias) * gate + xres), no pass over y for the average pool.  gate_ws: B*C floats of scratch. */
+int smos_channel_gate_apply_cl(const float* y, int64_t y_pitch, const float* bias, const float* w1, const float* b1,
+                               const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
+                               int64_t out_pitch, const float* chan_sums, int64_t chunks, float* gate_ws, int64_t B, int64_t C,
+                               int64_t Cr, int64_t HW, smos_stream_t stream);
 int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
                             const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
                             smos_stream_t stream);

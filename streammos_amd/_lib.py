@@ -44,7 +44,8 @@ SIGNATURES = {
     "smos_pointnet_scatter_rows": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
-    "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp],
+    "smos_conv_cl_sum_chunks": [i64, i64],
+    "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
@@ -57,6 +58,7 @@ SIGNATURES = {
     "smos_bias_act_cl": [vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, vp],
     "smos_downsample_epilogue_cl": [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_channel_gate_residual_cl": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, vp],
+    "smos_channel_gate_apply_cl": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, vp],
     "smos_upsample_concat_cl": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
     "smos_gather_scatter_cl": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
@@ -88,6 +90,7 @@ def load():
         fn.restype = ctypes.c_int
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
     lib.smos_stem_scan_state_words.restype = ctypes.c_int64
+    lib.smos_conv_cl_sum_chunks.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p

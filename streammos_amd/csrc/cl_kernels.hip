@@ -143,6 +143,52 @@ __global__ __launch_bounds__(kBlock) void gate_mlp(const float* __restrict__ par
   }
 }
 
+// The same gate from the per-row-segment channel sums that smos_conv_cl leaves behind (chan_sums: [B][chunks][C], four times
+// as many chunks as colsum_partial makes): 1024 threads per sample, the chunks of a channel shared by 1024 / C of them in a
+// fixed interleaved order, then the same two-layer MLP.
+__global__ __launch_bounds__(1024) void gate_mlp_wide(const float* __restrict__ partial, int chunks, const float* __restrict__ bias,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2, int C, int Cr,
+                                                      int64_t HW, float* __restrict__ gate) {
+  __shared__ float mean[256];
+  __shared__ float part_sum[1024];
+  __shared__ float hidden[64];
+  const int b = blockIdx.x;
+  const int parts = 1024 / C, c = threadIdx.x % C, part = threadIdx.x / C;
+  // eight independent chains per thread, their loads issued together: one block reads up to 256 KB here, and a single
+  // chain per thread is a string of dependent memory latencies (measured: the step got SLOWER than with the extra pass)
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* src = partial + (int64_t)b * chunks * C + c;
+  int k = part;
+  for (; k + 7 * parts < chunks; k += 8 * parts) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u * parts) * C];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += v[u];
+  }
+  for (int u = 0; k < chunks; k += parts, ++u) s[u & 7] += src[(int64_t)k * C];
+  part_sum[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.0f;
+    for (int q = 0; q < parts; ++q) t += part_sum[q * C + threadIdx.x];
+    mean[threadIdx.x] = t / (float)HW + bias[threadIdx.x];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
+    float h = b1[j];
+    for (int q = 0; q < C; ++q) h += w1[j * C + q] * mean[q];
+    hidden[j] = fmaxf(h, 0.0f);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < C; q += blockDim.x) {
+    float g = b2[q];
+    for (int j = 0; j < Cr; ++j) g += w2[q * Cr + j] * hidden[j];
+    gate[b * C + q] = 1.0f / (1.0f + expf(-g));
+  }
+}
+
 // out = relu((y + bias) * gate[b] + xres)
 __global__ __launch_bounds__(kBlock) void gate_apply_cl(const float* __restrict__ y, int64_t yp, const float* __restrict__ bias,
                                                         const float* __restrict__ gate, const float* __restrict__ xres,
@@ -402,6 +448,23 @@ extern "C" int smos_channel_gate_residual_cl(const float* y, int64_t y_pitch, co
   hipLaunchKernelGGL(gate_apply_cl, dim3(grid_for(B * HW * (C / 4), kBlock, 256 * 16)), dim3(kBlock), 0, s, y, y_pitch, bias,
                      (const float*)gate, xres, res_pitch, out, out_pitch, HW, (int)B, (int)(C / 4));
   return check_launch("channel_gate_residual_cl");
+}
+
+extern "C" int smos_channel_gate_apply_cl(const float* y, int64_t y_pitch, const float* bias, const float* w1, const float* b1,
+                                          const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
+                                          int64_t out_pitch, const float* chan_sums, int64_t chunks, float* gate_ws, int64_t B,
+                                          int64_t C, int64_t Cr, int64_t HW, smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && C <= 256 && 1024 % C == 0 && Cr > 0 && Cr <= 64 && HW > 0 && chunks > 0 &&
+                   chunks < (1LL << 24), "channel_gate_apply_cl: bad sizes (C must divide 1024, C <= 256, Cr <= 64)");
+  SMOS_REQUIRE(y && bias && w1 && b1 && w2 && b2 && xres && out && chan_sums && gate_ws, "channel_gate_apply_cl: null pointer");
+  SMOS_REQUIRE(al16(y) && al16(xres) && al16(out) && al16(bias) && al16(gate_ws) && y_pitch % 4 == 0 && res_pitch % 4 == 0 &&
+                   out_pitch % 4 == 0, "channel_gate_apply_cl: 16-byte alignment required");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gate_mlp_wide, dim3((unsigned)B), dim3(1024), 0, s, chan_sums, (int)chunks, bias, w1, b1, w2, b2, (int)C,
+                     (int)Cr, HW, gate_ws);
+  hipLaunchKernelGGL(gate_apply_cl, dim3(grid_for(B * HW * (C / 4), kBlock, 256 * 16)), dim3(kBlock), 0, s, y, y_pitch, bias,
+                     (const float*)gate_ws, xres, res_pitch, out, out_pitch, HW, (int)B, (int)(C / 4));
+  return check_launch("channel_gate_apply_cl");
 }
 
 extern "C" int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,

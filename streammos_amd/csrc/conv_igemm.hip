@@ -44,6 +44,7 @@ struct ConvArgs {
   const float* bias;   // [Cout] or null
   const float* res;    // [B, Ho, Wo, *] row pitch rp, or null
   float* out;          // [B, Ho, Wo, *] row pitch op
+  float* sums;         // SUMS: [B][hq * xt * 4][Cout] per-(item, row) channel sums of the output, or unused
   int64_t xp, rp, op;
   int B, H, W, Ho, Wo;
   int KH, KW, S, PH, PW;
@@ -105,12 +106,24 @@ __device__ __forceinline__ void ring_barrier() {
 #define SMOS_STAMP(k)
 #endif
 
+// Sum over the 32 lanes of each half wave, delivered in its last lane (31 / 63): four row_shr steps inside the 16-lane DPP
+// rows (an inclusive scan by doubling; lanes without a source read 0), then row_bcast:15 carries lane 15 / 47 into the next
+// row.  One fixed order, so the sums are run-to-run identical.
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+  return v;
+}
+
 struct ConvTile {      // where a wave's 32-pixel row segment lies (everything scalar; recomputed once per tile)
   int b, y, x0, ct;
   bool valid;
 };
 
-template <int MT, bool RES>
+template <int MT, bool RES, bool SUMS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 * MT float4, then Cout bias floats
   constexpr int kSlot = 256 * MT;
@@ -294,6 +307,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     const int pix = (t.b * a.Ho + t.y) * a.Wo + x;
     const int cbase = t.ct * 32 * MT + 4 * h;
     const unsigned ooff = store ? (unsigned)(pix * (int)a.op + cbase) * 4u : 0x80000000u;
+    // SUMS: this wave's row of the item = chunk ((y / 4) * xt + x0 / 32) * 4 + wave of sample b; a row past the image, or an
+    // item past the block's range, still writes its (zero) sums so that every chunk of the table is defined
+    float* srow = nullptr;
+    if constexpr (SUMS) {
+      const bool in_range = c_it < iters;
+      const int chunk = (((t.y - wave) >> 2) * a.xt + (t.x0 >> 5)) * 4 + wave;
+      srow = in_range ? a.sums + ((int64_t)t.b * (a.hq * a.xt * 4) + chunk) * a.cout + cbase : nullptr;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -309,6 +330,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
           // terms is always zero, so this is exact)
           o[c] = __builtin_fmaf(a.slope, fminf(v, 0.f), fmaxf(v, 0.f));
           acc[mt][4 * g + c] = 0.0f;
+        }
+        if constexpr (SUMS) {
+          float4 sv;
+          sv.x = half_wave_sum(store ? o[0] : 0.f);
+          sv.y = half_wave_sum(store ? o[1] : 0.f);
+          sv.z = half_wave_sum(store ? o[2] : 0.f);
+          sv.w = half_wave_sum(store ? o[3] : 0.f);
+          if (p == 31 && srow) *reinterpret_cast<float4*>(srow + mt * 32 + 8 * g) = sv;
         }
         u32x4 ov;
         ov.x = __float_as_uint(o[0]); ov.y = __float_as_uint(o[1]); ov.z = __float_as_uint(o[2]); ov.w = __float_as_uint(o[3]);
@@ -491,11 +520,11 @@ using namespace smos;
 
 static const int kDefaultBlocksPerCu[3] = {2, 2, 2};      // MT = 1, 2, 4
 
-template <int MT, bool RES>
+template <int MT, bool RES, bool SUMS = false>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float);
   KernelSetup ks;
-  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES>), 4 * 256 * MT * sizeof(float4) + 8192, 256, &ks, "conv_cl"))
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_igemm<MT, RES, SUMS>), 4 * 256 * MT * sizeof(float4) + 8192, 256, &ks, "conv_cl"))
     return rc;
   // Resident blocks per CU.  Alone on the GPU two are best (tools/ubench_conv.py); inside the two-stream step the other
   // stream's kernels need room on the CU to run beside a convolution at all.  SMOS_CONV_BLOCKS_PER_CU = "n" or "n1,n2,n4"
@@ -513,17 +542,19 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
-  hipLaunchKernelGGL((conv_igemm<MT, RES>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm<MT, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_cl");
 }
 
 // w: [Cout][Cin][KH][KW] reordered by ops.conv_prepare for the given MT.  x / res / out: channels-last rows with the given
 // pitches (floats), 16-byte aligned.  Replaces conv2d -> BatchNorm (folded) -> ReLU / LeakyReLU (-> + residual -> ReLU) of
 // networks/backbone.py:136-159 and multi_view_encoder.py:460-497 in one launch.
+extern "C" int64_t smos_conv_cl_sum_chunks(int64_t Ho, int64_t Wo) { return ((Ho + 3) / 4) * ((Wo + 31) / 32) * 4; }
+
 extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res,
                             int64_t res_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin,
                             int64_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt,
-                            int32_t act, smos_stream_t stream) {
+                            int32_t act, float* chan_sums, smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && (mt == 1 || mt == 2 || mt == 4) &&
                    Cout % (32 * mt) == 0, "conv_cl: Cin must be a multiple of 32 and Cout of 32 * mt (mt in {1, 2, 4})");
   SMOS_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && (stride == 1 || stride == 2) && pad_h >= 0 && pad_w >= 0 &&
@@ -540,7 +571,7 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
                    (!res || B * Ho * Wo * res_pitch * 4 < (1LL << 31)), "conv_cl: a tensor larger than 2 GiB (32-bit buffer offsets)");
   SMOS_REQUIRE(B * hq * xt * nct < (1LL << 30) && (int64_t)KH * KW * (Cin / 32) * nct < (1LL << 20), "conv_cl: too many tiles");
   ConvArgs a;
-  a.x = x; a.w = reinterpret_cast<const float4*>(wprep); a.bias = bias; a.res = res; a.out = out;
+  a.x = x; a.w = reinterpret_cast<const float4*>(wprep); a.bias = bias; a.res = res; a.out = out; a.sums = chan_sums;
   a.xp = x_pitch; a.rp = res_pitch; a.op = out_pitch;
   a.B = (int)B; a.H = (int)H; a.W = (int)W; a.Ho = (int)Ho; a.Wo = (int)Wo;
   a.KH = KH; a.KW = KW; a.S = stride; a.PH = pad_h; a.PW = pad_w;
@@ -557,6 +588,12 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
   a.r_bytes = res ? (int)(B * Ho * Wo * res_pitch * 4) : 0;
   a.o_bytes = (int)(B * Ho * Wo * out_pitch * 4);
   a.cout = (int)Cout;
+  if (chan_sums) {
+    SMOS_REQUIRE(!res && (reinterpret_cast<uintptr_t>(chan_sums) & 15) == 0, "conv_cl: channel sums need res == NULL and 16-byte alignment");
+    if (mt == 1) return launch_conv<1, false, true>(a, (hipStream_t)stream);
+    if (mt == 2) return launch_conv<2, false, true>(a, (hipStream_t)stream);
+    return launch_conv<4, false, true>(a, (hipStream_t)stream);
+  }
   if (res) {
     SMOS_REQUIRE(mt <= 2, "conv_cl: a residual input needs mt <= 2 (register budget)");
     return mt == 1 ? launch_conv<1, true>(a, (hipStream_t)stream) : launch_conv<2, true>(a, (hipStream_t)stream);

@@ -151,6 +151,7 @@ class InferenceEngine:
         # epilogue fused (csrc/conv_igemm.hip).  SMOS_OWN_CONV=0 falls back to MIOpen convs + separate epilogue passes
         # (kept for A/B runs; tools/ubench_conv.py compares the two per layer).
         self.own_conv = os.environ.get("SMOS_OWN_CONV", "1") != "0"
+        self.fused_gate_sums = os.environ.get("SMOS_GATE_SUMS", "1") != "0"      # ChannelAtt pool sums from the conv epilogue
         self._wprep = {}
         self._shapes = None
         self._lsi = None
@@ -358,7 +359,7 @@ class InferenceEngine:
             return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
-    def _conv(self, x, w, bias, act, stride=1, residual=None, out=None):
+    def _conv(self, x, w, bias, act, stride=1, residual=None, out=None, chan_sums=None):
         """act(conv(x, w) + bias [+ residual]) for a folded weight w [Cout, Cin, KH, KW] ("same" padding for odd kernels)
         on channels-last maps: one launch of csrc/conv_igemm.hip; the operand-ordered copy of w is made once per (weight,
         mt).  With SMOS_OWN_CONV=0: MIOpen conv + the separate bias / activation / residual pass."""
@@ -375,7 +376,7 @@ class InferenceEngine:
         wp = self._wprep.get(key)
         if wp is None:
             wp = self._wprep[key] = ops.conv_prepare(w, mt)
-        return ops.conv_cl(x, wp, bias, act, cout, (kh, kw), stride=stride, mt=mt, residual=residual, out=out)
+        return ops.conv_cl(x, wp, bias, act, cout, (kh, kw), stride=stride, mt=mt, residual=residual, out=out, chan_sums=chan_sums)
 
     def _block_cl(self, x, p, out=None):
         if p.kind == "down":
@@ -391,6 +392,15 @@ class InferenceEngine:
         y = self._conv(x, p.w1, p.b1, RELU)
         if not p.att:
             return self._conv(y, p.w2, p.b2, RELU, residual=x, out=out)
+        bsz, c, h, w = y.shape
+        if self.own_conv and self.fused_gate_sums and c % 32 == 0 and 1024 % c == 0:
+            # the conv's epilogue leaves the per-row-segment channel sums behind: no pass over y2 for the average pool
+            chunks = ops.conv_sum_chunks(h, w)
+            ws = self._block_ws(p, bsz * c * (chunks + 1))
+            sums = ws[:bsz * chunks * c].view(bsz, chunks, c)
+            y2 = self._conv(y, p.w2, None, NONE, chan_sums=sums)
+            return ops.channel_gate_apply_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, sums, ws[bsz * chunks * c:],
+                                             out=out if out is not None else y2)
         y2 = self._conv(y, p.w2, None, NONE)
         need = (y2.shape[2] * y2.shape[3] // 512 + 2) * y2.shape[0] * y2.shape[1]
         return ops.channel_gate_residual_cl(y2, p.b2, p.cw1, p.cb1, p.cw2, p.cb2, x, self._block_ws(p, need),

@@ -488,10 +488,17 @@ def conv_mt(cout, n_pixels, residual=False):
     return 1
 
 
-def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, residual=None, out=None):
+def conv_sum_chunks(ho, wo):
+    """Row segments per sample in the channel-sum table of conv_cl(..., chan_sums=...)."""
+    return ((ho + 3) // 4) * ((wo + 31) // 32) * 4
+
+
+def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, residual=None, out=None, chan_sums=None):
     """act(conv(x) + bias [+ residual]) on channels-last [B,C,H,W] views in one launch (csrc/conv_igemm.hip).
-    wprep = conv_prepare(w, mt); kernel = (KH, KW); padding defaults to "same" for odd kernels."""
-    _require_cuda("conv_cl", x, wprep, bias, residual, out)
+    wprep = conv_prepare(w, mt); kernel = (KH, KW); padding defaults to "same" for odd kernels.
+    chan_sums: optional float32 [B, conv_sum_chunks(Ho, Wo), Cout] that receives the per-row-segment channel sums of the
+    output (the average-pool input of a ChannelAtt block); not together with a residual."""
+    _require_cuda("conv_cl", x, wprep, bias, residual, out, chan_sums)
     b, cin, h, w = x.shape
     kh, kw = kernel
     ph, pw = padding if padding is not None else (kh // 2, kw // 2)
@@ -504,16 +511,20 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
         raise RuntimeError("conv_cl: out has shape %s, expected %s" % (tuple(out.shape), (b, cout, ho, wo)))
     if residual is not None and tuple(residual.shape) != (b, cout, ho, wo):
         raise RuntimeError("conv_cl: residual has shape %s" % (tuple(residual.shape),))
+    if chan_sums is not None and (residual is not None or not chan_sums.is_contiguous() or chan_sums.dtype != torch.float32 or
+                                  tuple(chan_sums.shape) != (b, conv_sum_chunks(ho, wo), cout)):
+        raise RuntimeError("conv_cl: chan_sums must be contiguous float32 [B, conv_sum_chunks(Ho, Wo), Cout], without a residual")
     lib = _lib.load()
     label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, ho, wo, kh, kw, "+res" if residual is not None else "")
     args = (x.data_ptr(), _cl("conv_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             residual.data_ptr() if residual is not None else None, _cl("conv_cl", residual) if residual is not None else 0,
-            out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act))
+            out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act),
+            chan_sums.data_ptr() if chan_sums is not None else None)
     with torch.cuda.device(x.device), profiling.span(label):
         rc = lib.smos_conv_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_cl")
     if profiling._replay_label == label:
-        keep = (x, wprep, bias, residual, out)          # the closure keeps the operands alive
+        keep = (x, wprep, bias, residual, out, chan_sums)          # the closure keeps the operands alive
 
         def again(keep=keep):
             with torch.cuda.device(keep[0].device), profiling.span(label):
@@ -854,6 +865,26 @@ def channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xres, ws, out=None):
                                                _cl("channel_gate_residual_cl", out), ws.data_ptr(), ws.numel(), b, c, w1.shape[0],
                                                h * w, _stream(y))
     _lib.check(rc, "smos_channel_gate_residual_cl")
+    return out
+
+
+def channel_gate_apply_cl(y, bias, w1, b1, w2, b2, xres, chan_sums, gate_ws, out=None):
+    """ChannelAtt + residual + ReLU from the channel sums conv_cl left in chan_sums [B, chunks, C]: gate MLP, then
+    out = relu((y + bias) * gate + xres).  gate_ws: >= B*C floats of scratch."""
+    _require_cuda("channel_gate_apply_cl", y, bias, w1, b1, w2, b2, xres, chan_sums, gate_ws, out)
+    b, c, h, w = y.shape
+    if chan_sums.dim() != 3 or chan_sums.shape[0] != b or chan_sums.shape[2] != c or not chan_sums.is_contiguous() or gate_ws.numel() < b * c:
+        raise RuntimeError("channel_gate_apply_cl: chan_sums must be contiguous [B, chunks, C] and gate_ws hold B*C floats")
+    if out is None:
+        out = empty_cl(b, c, h, w, y.device)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        rc = lib.smos_channel_gate_apply_cl(y.data_ptr(), _cl("channel_gate_apply_cl", y), bias.data_ptr(), w1.data_ptr(),
+                                            b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), xres.data_ptr(),
+                                            _cl("channel_gate_apply_cl", xres), out.data_ptr(), _cl("channel_gate_apply_cl", out),
+                                            chan_sums.data_ptr(), chan_sums.shape[1], gate_ws.data_ptr(), b, c, w1.shape[0], h * w,
+                                            _stream(y))
+    _lib.check(rc, "smos_channel_gate_apply_cl")
     return out
 
 

@@ -647,6 +647,51 @@ def test_conv_cl_is_deterministic_and_batch_independent():
     assert torch.equal(a, b) and torch.equal(a[1:2], c)
 
 
+@pytest.mark.parametrize("cin,cout,hw,mt", [(32, 32, (40, 64), 1), (64, 64, (13, 45), 2), (128, 128, (16, 32), 4),
+                                            (64, 64, (13, 45), 1), (32, 32, (3, 8), 1)])
+def test_conv_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mt):
+    """conv_cl(chan_sums=...): the epilogue also leaves the channel sums of every 32-pixel output row segment (DPP reduction
+    in a fixed order; segments and rows outside the image hold 0), and channel_gate_apply_cl builds ChannelAtt + residual
+    (networks/backbone.py:57-73, 87-102) on them -- against float64 and against the three-pass kernel it replaces."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(71)
+    b, (h, w) = 3, hw
+    x = torch.randn((b, h, w, cin), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (cin * 9)) ** 0.5).to(DEV)
+    chunks = ops.conv_sum_chunks(h, w)
+    sums = torch.full((b, chunks, cout), 7.0, device=DEV)
+    y = ops.conv_cl(x, ops.conv_prepare(wt, mt), None, 0, cout, (3, 3), mt=mt, chan_sums=sums)
+    y_plain = ops.conv_cl(x, ops.conv_prepare(wt, mt), None, 0, cout, (3, 3), mt=mt)
+    assert torch.equal(y, y_plain)                                        # the output itself is untouched
+    # segment sums: chunk = ((y // 4) * ceil(W / 32) + x // 32) * 4 + y % 4
+    xt = (w + 31) // 32
+    want = torch.zeros((b, chunks, cout), dtype=torch.float64, device=DEV)
+    yd = y.double()
+    for yy in range(h):
+        for t in range(xt):
+            want[:, ((yy // 4) * xt + t) * 4 + yy % 4] = yd[:, :, yy, 32 * t:32 * t + 32].sum(-1)
+    scale = yd.abs().sum((2, 3)).max().item() / (h * xt)
+    assert (sums.double() - want).abs().max().item() <= 1e-5 * scale
+    sums2 = torch.empty_like(sums)
+    ops.conv_cl(x, ops.conv_prepare(wt, mt), None, 0, cout, (3, 3), mt=mt, chan_sums=sums2)
+    assert torch.equal(sums, sums2)                                       # fixed summation order
+    assert (sums.sum(1).double() - yd.sum((2, 3))).abs().max().item() <= 1e-5 * yd.abs().sum((2, 3)).max().item()
+    # the gate on top of them
+    cr = max(cout // 4, 8)
+    bias, b1, b2 = (torch.randn(n, generator=gen).to(DEV) for n in (cout, cr, cout))
+    w1 = (torch.randn((cr, cout), generator=gen) * 0.3).to(DEV)
+    w2 = (torch.randn((cout, cr), generator=gen) * 0.3).to(DEV)
+    xres = torch.randn((b, h, w, cout), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    got = ops.channel_gate_apply_cl(y, bias, w1, b1, w2, b2, xres, sums, torch.empty(b * cout, device=DEV))
+    z = yd + bias.double()[None, :, None, None]
+    g = torch.sigmoid(F.linear(F.relu(F.linear(z.mean((2, 3)), w1.double(), b1.double())), w2.double(), b2.double()))
+    ref = F.relu(z * g[:, :, None, None] + xres.double())
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    ws = torch.zeros(b * cout * (h * w // 512 + 2), device=DEV)
+    old = ops.channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xres, ws)
+    assert (got - old).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
 def _binding(kind, name):
     """The ctypes-backed Python module refapi.install() publishes under the reference's pybind name, or the COMPILED
     pybind11 twin (csrc/shim/pybind_shims.cpp = INTEGRATION.md section 3, built by __graft_entry__.build())."""
