@@ -134,48 +134,77 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
 
   // inputs of one column tile: 4 features per lane + the two grid coordinates of the lane's point
   struct TileIn {
-    float x[4], cy, cx;
+    float x[4], cy, cx;      // as loaded: the selects that turn them into operands are applied where they are consumed --
+    bool has;                // applied here, hipcc hoists them right behind the loads and the prefetch is waited for at once
   };
+  // Every load of the software pipeline is an UNCONDITIONAL raw buffer load: a lane without a point uses an offset past
+  // the end of the buffer and reads 0.  Written as "has ? ptr[i] : 0" the loads sit under lane-dependent branches, hipcc's
+  // wait-count pass loses track of them and puts s_waitcnt vmcnt(0) in front of the next vector-memory-dependent
+  // instruction -- here right behind the prefetch, so every tile sat through a full memory latency before its matrix
+  // phase (ISA: vmcnt(0) 30 instructions after the loads; MFMA busy 36 %).
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xyzi), 0, a.S * 7 * a.N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.coord), 0, a.S * a.N * a.K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t*>(a.row_of), 0, a.row_of ? (a.S / a.T) * a.H * a.W * 4 : 0, 0x00020000);
+  constexpr unsigned kOob = 0x80000000u;
   auto fetch = [&](int nt, TileIn& in) {
     const bool live = nt < n_nt;
     const int s = live ? nt / nt_per_sample : 0;
     const int n0 = live ? (nt - s * nt_per_sample) * kNt : 0;
-    const bool has = live && n0 + col < a.N;
-    const float* xs = a.xyzi + (int64_t)s * 7 * a.N + n0;          // wave-uniform base, per-lane offset below
-    const int lane_off = hh * a.N + col;
+    const bool has = live & (n0 + col < a.N);
+    const unsigned xoff = (unsigned)((s * 7 + hh) * a.N + n0 + col) * 4u;      // feature f = 2 q + hh of the lane's point
+    const unsigned fstep = (unsigned)a.N * 8u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int f = 2 * q + hh;
-      in.x[q] = f < 7 ? (has ? xs[(int64_t)2 * q * a.N + lane_off] : 0.0f) : 1.0f;
+      const bool ok = has & (2 * q + hh < 7);
+      in.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrd, ok ? xoff + fstep * q : kOob, 0, 0));
     }
-    const float* cr = a.coord + ((int64_t)s * a.N + n0) * a.K;
-    in.cy = has ? cr[col * a.K] : -1.0f;   // -1 is outside the half-open test of cell_2d
-    in.cx = has ? cr[col * a.K + 1] : -1.0f;
+    const unsigned coff = has ? (unsigned)((s * a.N + n0 + col) * a.K) * 4u : kOob;
+    in.cy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(csrd, coff, 0, 0));
+    in.cx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(csrd, coff + 4u, 0, 0));      // (the last argument is the cache policy)
+    in.has = has;
   };
 
   // target slot of the lane's point: its cell of the dense grid, or (compact target) the row of that cell -- looked up
   // here, per lane and inside the prefetch shadow, not in the serial flush loop.  Equal cells <=> equal rows, so the
   // run detection works on either.
-  auto cell_of = [&](const TileIn& in, int tile) {
-    const float yx[2] = {in.cy, in.cx};
-    int c = cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
-    if (a.row_of && c >= 0) c = a.row_of[(int64_t)((tile / nt_per_sample) / a.T) * a.H * a.W + c];
-    return c;
+  // split in two: the request (cell from the coordinates + the row lookup issued) and the resolve (first use of the
+  // looked-up row), so that a whole matrix phase lies between them
+  auto cell_request = [&](const TileIn& in, int tile, int& c, int& r) {
+    const float yx[2] = {in.has ? in.cy : -1.0f, in.has ? in.cx : -1.0f};   // -1 is outside the half-open test of cell_2d
+    c = cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
+    const unsigned roff = (c >= 0) ? (unsigned)(((tile / nt_per_sample) / a.T) * a.H * a.W + c) * 4u : kOob;
+    r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, roff, 0, 0);      // no row table: zero-sized buffer, reads 0
   };
+  auto cell_resolve = [&](int c, int r) { return (a.row_of != nullptr) & (c >= 0) ? r : c; };
   int nt = (int)blockIdx.x * (kBlock / kWave) + wave_u;
-  TileIn cur;
+  TileIn cur, nxt;
   fetch(nt, cur);
-  int cell = cell_of(cur, nt);
+  fetch(nt + nt_step, nxt);
+  int cell;
+  {
+    int c0, r0;
+    cell_request(cur, nt, c0, r0);
+    cell = cell_resolve(c0, r0);
+    // everything the loop carries has landed before the first trip: otherwise the loop header inherits pending loads from
+    // this path, and the wait the compiler puts there is, on the back edge, a wait for the previous tile's atomics
+    asm volatile("" : "+v"(cur.x[0]), "+v"(cur.x[1]), "+v"(cur.x[2]), "+v"(cur.x[3]), "+v"(nxt.x[0]), "+v"(nxt.x[1]), "+v"(nxt.x[2]),
+                 "+v"(nxt.x[3]), "+v"(nxt.cy), "+v"(nxt.cx), "+v"(cell));
+  }
   for (; nt < n_nt; nt += nt_step) {
-    // Software pipeline: the next tile's loads are issued here and waited for after this tile's matrix phase, BEFORE
-    // this tile's stores and atomics are issued.  The vector-memory counter of gfx9 retires in order and the number of
-    // atomics is data dependent, so a wait placed after them would be a wait for all of them (vmcnt(0)).
-    TileIn nxt;
-    fetch(nt + nt_step, nxt);
+    // Software pipeline, two tiles deep: the inputs of tile + 2 and the row lookup of tile + 1 (whose coordinates arrived
+    // during the previous matrix phase) are requested here and waited for after this tile's matrix phase, BEFORE this
+    // tile's stores and atomics are issued.  The vector-memory counter of gfx9 retires in order and the number of atomics
+    // is data dependent, so a wait placed after them is a wait for all of them (vmcnt(0)) -- with a one-deep pipeline the
+    // looked-up row of the next tile was exactly such a wait at the loop's back edge.
+    TileIn nn;
+    fetch(nt + 2 * nt_step, nn);
+    int c_next, r_next;
+    cell_request(nxt, nt + nt_step, c_next, r_next);
     const int s = nt / nt_per_sample;
     const int n0 = (nt - s * nt_per_sample) * kNt;
     const int b = s / a.T, t = s - b * a.T;
-    float xk[4] = {cur.x[0], cur.x[1], cur.x[2], cur.x[3]};
+    float xk[4] = {cur.x[0], cur.x[1], cur.x[2], hh ? 1.0f : cur.x[3]};      // feature 7 = 1 carries the folded layer-1 bias
     // the shuffle is its own statement: inside the short-circuit expression it would run with lane 31 masked off, and
     // a lane that reads a masked-off lane gets 0 -- indistinguishable from cell 0
     const int cell_after = __shfl_down(cell, 1);
@@ -183,9 +212,12 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     // a tile none of whose points falls into the grid (the padding tail of a scan: 25-40 % of the rows) produces nothing
     // unless its point rows are wanted (t == 0): skip the matrix work, keep the software pipeline moving
     if (!(a.pts_out && t == 0) && __ballot(cell >= 0) == 0) {
-      const int cell_skip = cell_of(nxt, nt + nt_step);
+      // (waited for on this path too: the register copies of the rotation sit in the shared loop latch, and a wait placed
+      // there would run on the main path as well -- as a wait for its atomics)
+      asm volatile("" : "+v"(nn.x[0]), "+v"(nn.x[1]), "+v"(nn.x[2]), "+v"(nn.x[3]), "+v"(nn.cy), "+v"(nn.cx), "+v"(r_next));
+      cell = cell_resolve(c_next, r_next);
       cur = nxt;
-      cell = cell_skip;
+      nxt = nn;
       continue;
     }
 
@@ -236,8 +268,8 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
 #pragma unroll
     for (int i = 0; i < kNt; ++i) v[i] = tile[i * kPitchM + lane];
     // the prefetch is waited for here (tied to the last LDS read so that the scheduler cannot hoist the wait)
-    asm volatile("" : "+v"(nxt.x[0]), "+v"(nxt.x[1]), "+v"(nxt.x[2]), "+v"(nxt.x[3]), "+v"(nxt.cy), "+v"(nxt.cx), "+v"(v[kNt - 1]));
-    const int cell_next = cell_of(nxt, nt + nt_step);
+    asm volatile("" : "+v"(nn.x[0]), "+v"(nn.x[1]), "+v"(nn.x[2]), "+v"(nn.x[3]), "+v"(nn.cy), "+v"(nn.cx), "+v"(r_next), "+v"(v[kNt - 1]));
+    const int cell_next = cell_resolve(c_next, r_next);
     if (a.pts_out && t == 0) {
       float* prow = a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n;   // wave-uniform
       if (n_valid == kNt) {
@@ -265,6 +297,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     }
     wave_sync();
     cur = nxt;
+    nxt = nn;
     cell = cell_next;
   }
 }
@@ -391,6 +424,8 @@ static int pointnet_scatter_launch(const float* xyzi, const float* coord, int32_
   SMOS_REQUIRE(B > 0 && T > 0 && N > 0 && H > 0 && W > 0 && K >= 2, "pointnet_scatter: bad sizes");
   SMOS_REQUIRE(xyzi && coord && w1 && b1 && w2 && b2 && bev, "pointnet_scatter: null pointer");
   SMOS_REQUIRE(H * W < (1LL << 31) && (!pts_out || po_n >= 64), "pointnet_scatter: bad geometry");
+  SMOS_REQUIRE(B * T * 7 * N * 4 < (1LL << 31) && B * T * N * K * 4 < (1LL << 31) && B * H * W * 4 < (1LL << 31),
+               "pointnet_scatter: an input larger than 2 GiB (32-bit buffer offsets)");
   PnsArgs a;
   a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.row_of = row_of; a.pts_out = pts_out;
   a.bev_sb = H * W * T * 64; a.po_b = po_b; a.po_n = po_n;
