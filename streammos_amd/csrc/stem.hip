@@ -244,21 +244,26 @@ struct StemEpiArgs {
 template <int kC>
 __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
   const int c = threadIdx.x % kC;
-  const int64_t n_out = (int64_t)a.B * a.Ho * a.Wo;
+  const int n_out = a.B * a.Ho * a.Wo;            // < 2^31 (host check): 32-bit index arithmetic throughout
   const float bias = a.bias[c];
   const int start[4] = {a.meta[4], a.meta[5], a.meta[6], a.meta[7]};
-  for (int64_t o = (int64_t)blockIdx.x * (kBlock / kC) + threadIdx.x / kC; o < n_out; o += (int64_t)gridDim.x * (kBlock / kC)) {
-    const int wo = (int)(o % a.Wo);
-    const int64_t t = o / a.Wo;
-    const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+  // the nine row ids come through a raw buffer descriptor: a tap outside the grid uses an offset past the end (reads 0)
+  // instead of sitting under a lane-dependent branch -- nine conditional loads were nine exec-masked branches, each followed
+  // by a full wait
+  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.row_of), 0, a.B * a.H * a.W * 4, 0x00020000);
+  for (int o = (int)blockIdx.x * (kBlock / kC) + (int)threadIdx.x / kC; o < n_out; o += (int)gridDim.x * (kBlock / kC)) {
+    const int wo = o % a.Wo;
+    const int t = o / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
     // all nine row ids first, then all eighteen loads (an empty or out-of-range tap reads row 0 of its class and is
     // discarded by the selects), then the sums in fixed tap order
     int rid[9];
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
       const int y = 2 * ho - 1 + t9 / 3, x = 2 * wo - 1 + t9 % 3;
-      const bool inb = y >= 0 && y < a.H && x >= 0 && x < a.W;
-      rid[t9] = inb ? a.row_of[((int64_t)b * a.H + y) * a.W + x] : -2;     // -1: empty cell, -2: outside the grid
+      const bool inb = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+      const int r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, inb ? (unsigned)((b * a.H + y) * a.W + x) * 4u : 0x80000000u, 0, 0);
+      rid[t9] = inb ? r : -2;     // -1: empty cell, -2: outside the grid
     }
     float va[9], vq[9];
 #pragma unroll
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
       // an empty cell inside the grid contributes 0 to the pooled branch; outside the grid nothing (padding of the pool)
       qmax = rid[t9] >= 0 ? fmaxf(qmax, vq[t9]) : (rid[t9] == -1 ? fmaxf(qmax, 0.0f) : qmax);
     }
-    a.out[o * a.op + c] = fmaxf((acc + qmax) + bias, 0.0f);
+    a.out[(int64_t)o * a.op + c] = fmaxf((acc + qmax) + bias, 0.0f);
   }
 }
 
@@ -352,6 +357,7 @@ extern "C" int smos_stem_epilogue(const float* const* y4, const int32_t* meta, c
                                   float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && H > 1 && W > 1 && C == 32 && out_pitch >= C, "stem_epilogue: bad sizes (C must be 32)");
   SMOS_REQUIRE(y4 && meta && row_of && bias && out, "stem_epilogue: null pointer");
+  SMOS_REQUIRE(B * H * W < (1LL << 29), "stem_epilogue: grid too large for 32-bit buffer offsets");
   StemEpiArgs a;
   for (int k = 0; k < 4; ++k) a.y[k] = y4[k];
   a.meta = meta; a.row_of = row_of; a.bias = bias; a.out = out; a.op = out_pitch;
