@@ -34,72 +34,93 @@ __device__ __forceinline__ Lerp lerp_of(int dst, int n_src, int n_dst) {
   return l;
 }
 
+// Both passes issue ALL their loads unconditionally and up front: a tap that leaves the image reads a clamped (valid)
+// address and enters with weight 0.  Written with "if (outside) continue" every tap's pair of loads sat under its own
+// lane-dependent branch, and hipcc's wait-count pass answered each with s_waitcnt vmcnt(0): six to seven serialised memory
+// round trips per output.  Index arithmetic is 32-bit (the host checks the element counts), addresses 64-bit.
+
 // z [B, Hs, Ws, 9*C] (tap-major blocks of C channels), t [B, 3, Hs, Wo, C]; one thread = 4 channels of one (b, ky, ys, X)
 __global__ __launch_bounds__(kBlock) void upconv_xpass(const float* __restrict__ z, float* __restrict__ t, int B, int Hs, int Ws,
                                                        int C4, int Wo) {
-  const int64_t total = (int64_t)B * 3 * Hs * Wo * C4;
+  const int total = B * 3 * Hs * Wo * C4;
   const int C = C4 * 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4) * 4;
-    int64_t r = i / C4;
-    const int X = (int)(r % Wo);
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
+    const int q = (i % C4) * 4;
+    int r = i / C4;
+    const int X = r % Wo;
     r /= Wo;
-    const int ys = (int)(r % Hs);
+    const int ys = r % Hs;
     r /= Hs;
-    const int ky = (int)(r % 3), b = (int)(r / 3);
-    const float* zrow = z + (((int64_t)b * Hs + ys) * Ws) * (9 * C) + (3 * ky) * C + q;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ky = r % 3, b = r / 3;
+    const float* zrow = z + ((int64_t)(b * Hs + ys) * Ws) * (9 * C) + (3 * ky) * C + q;
+    float4 v0[3], v1[3];
+    float w0[3], w1[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xs = X + kx - 1;
-      if (xs < 0 || xs >= Wo) continue;          // zero padding of the convolution, at the upsampled resolution
-      const Lerp l = lerp_of(xs, Ws, Wo);
+      const bool in = (xs >= 0) & (xs < Wo);          // zero padding of the convolution, at the upsampled resolution
+      const Lerp l = lerp_of(min(max(xs, 0), Wo - 1), Ws, Wo);
       const float* p = zrow + (int64_t)l.i0 * (9 * C) + kx * C;
-      const float4 v0 = *reinterpret_cast<const float4*>(p);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)l.step * (9 * C));
-      acc.x += l.w0 * v0.x + l.w1 * v1.x; acc.y += l.w0 * v0.y + l.w1 * v1.y;
-      acc.z += l.w0 * v0.z + l.w1 * v1.z; acc.w += l.w0 * v0.w + l.w1 * v1.w;
+      v0[kx] = *reinterpret_cast<const float4*>(p);
+      v1[kx] = *reinterpret_cast<const float4*>(p + (int64_t)l.step * (9 * C));
+      w0[kx] = in ? l.w0 : 0.0f;
+      w1[kx] = in ? l.w1 : 0.0f;
     }
-    *reinterpret_cast<float4*>(t + i * 4) = acc;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      acc.x += w0[kx] * v0[kx].x + w1[kx] * v1[kx].x; acc.y += w0[kx] * v0[kx].y + w1[kx] * v1[kx].y;
+      acc.z += w0[kx] * v0[kx].z + w1[kx] * v1[kx].z; acc.w += w0[kx] * v0[kx].w + w1[kx] * v1[kx].w;
+    }
+    *reinterpret_cast<float4*>(t + (int64_t)i * 4) = acc;
   }
 }
 
 struct YSrc {
-  const float* t;   // [B, 3, Hs, Wo, C] or null
+  const float* t;   // [B, 3, Hs, Wo, C]; an absent source is passed as a copy of the other one with on = 0
   int Hs;
+  float on;         // 1 / 0
 };
 
 // out = act(conv_a + bias + sum over the sources and ky of the y-interpolated x-pass rows); act: 0 none, 1 ReLU, 2 LeakyReLU(0.01)
 __global__ __launch_bounds__(kBlock) void upconv_ypass(const float* __restrict__ conv_a, int64_t ap, const float* __restrict__ bias,
                                                        YSrc s1, YSrc s2, float* __restrict__ out, int64_t op, int B, int Ho, int Wo,
                                                        int C4, int act) {
-  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  const int total = B * Ho * Wo * C4;
   const int C = C4 * 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4) * 4;
-    int64_t r = i / C4;
-    const int X = (int)(r % Wo);
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
+    const int q = (i % C4) * 4;
+    int r = i / C4;
+    const int X = r % Wo;
     r /= Wo;
-    const int Y = (int)(r % Ho), b = (int)(r / Ho);
-    const int64_t pix = ((int64_t)b * Ho + Y) * Wo + X;
+    const int Y = r % Ho, b = r / Ho;
+    const int64_t pix = (int64_t)(b * Ho + Y) * Wo + X;
     float4 acc = *reinterpret_cast<const float4*>(conv_a + pix * ap + q);
+    const float4 bv = *reinterpret_cast<const float4*>(bias + q);
+    float4 v0[2][3], v1[2][3];
+    float w0[2][3], w1[2][3];
 #pragma unroll
     for (int si = 0; si < 2; ++si) {
       const YSrc s = si == 0 ? s1 : s2;
-      if (!s.t) continue;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int ysrc = Y + ky - 1;
-        if (ysrc < 0 || ysrc >= Ho) continue;
-        const Lerp l = lerp_of(ysrc, s.Hs, Ho);
-        const float* p = s.t + ((((int64_t)b * 3 + ky) * s.Hs + l.i0) * Wo + X) * C + q;
-        const float4 v0 = *reinterpret_cast<const float4*>(p);
-        const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)l.step * Wo * C);
-        acc.x += l.w0 * v0.x + l.w1 * v1.x; acc.y += l.w0 * v0.y + l.w1 * v1.y;
-        acc.z += l.w0 * v0.z + l.w1 * v1.z; acc.w += l.w0 * v0.w + l.w1 * v1.w;
+        const bool in = (ysrc >= 0) & (ysrc < Ho);
+        const Lerp l = lerp_of(min(max(ysrc, 0), Ho - 1), s.Hs, Ho);
+        const float* p = s.t + ((int64_t)((b * 3 + ky) * s.Hs + l.i0) * Wo + X) * C + q;
+        v0[si][ky] = *reinterpret_cast<const float4*>(p);
+        v1[si][ky] = *reinterpret_cast<const float4*>(p + (int64_t)l.step * Wo * C);
+        w0[si][ky] = in ? l.w0 * s.on : 0.0f;
+        w1[si][ky] = in ? l.w1 * s.on : 0.0f;
       }
     }
-    const float4 bv = *reinterpret_cast<const float4*>(bias + q);
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc.x += w0[si][ky] * v0[si][ky].x + w1[si][ky] * v1[si][ky].x; acc.y += w0[si][ky] * v0[si][ky].y + w1[si][ky] * v1[si][ky].y;
+        acc.z += w0[si][ky] * v0[si][ky].z + w1[si][ky] * v1[si][ky].z; acc.w += w0[si][ky] * v0[si][ky].w + w1[si][ky] * v1[si][ky].w;
+      }
     float4 o = make_float4(acc.x + bv.x, acc.y + bv.y, acc.z + bv.z, acc.w + bv.w);
     if (act == 1) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
@@ -121,6 +142,7 @@ extern "C" int smos_upconv_xpass(const float* z, float* t, int64_t B, int64_t Hs
                                  smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 4 == 0 && Wo > 0, "upconv_xpass: bad sizes (C %% 4 must be 0)");
   SMOS_REQUIRE(z && t && aligned16(z) && aligned16(t), "upconv_xpass: null / unaligned pointer");
+  SMOS_REQUIRE(B * 3 * Hs * Wo * (C / 4) < (1LL << 31) && B * Hs < (1LL << 31), "upconv_xpass: too many elements for 32-bit indices");
   hipLaunchKernelGGL(upconv_xpass, dim3(grid_for(B * 3 * Hs * Wo * (C / 4), kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, z, t,
                      (int)B, (int)Hs, (int)Ws, (int)(C / 4), (int)Wo);
   return check_launch("upconv_xpass");
@@ -133,7 +155,10 @@ extern "C" int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const flo
                "upconv_ypass: bad arguments");
   SMOS_REQUIRE(conv_a && bias && out && aligned16(conv_a) && aligned16(out) && aligned16(bias) && (!t1 || (aligned16(t1) && H1 > 0)) &&
                    (!t2 || (aligned16(t2) && H2 > 0)), "upconv_ypass: null / unaligned pointer");
-  YSrc s1{t1, (int)H1}, s2{t2, (int)H2};
+  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < (1LL << 31) && (t1 || t2) && B * 3 * (H1 > H2 ? H1 : H2) < (1LL << 31),
+               "upconv_ypass: too many elements for 32-bit indices / no source");
+  // an absent source: the other one again, switched off -- every load of the kernel stays unconditional
+  YSrc s1{t1 ? t1 : t2, (int)(t1 ? H1 : H2), t1 ? 1.0f : 0.0f}, s2{t2 ? t2 : t1, (int)(t2 ? H2 : H1), t2 ? 1.0f : 0.0f};
   hipLaunchKernelGGL(upconv_ypass, dim3(grid_for(B * Ho * Wo * (C / 4), kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, conv_a,
                      a_pitch, bias, s1, s2, out, out_pitch, (int)B, (int)Ho, (int)Wo, (int)(C / 4), (int)act);
   return check_launch("upconv_ypass");
