@@ -47,27 +47,31 @@ __global__ __launch_bounds__(kBlock) void downsample_epilogue_cl2(const float* _
                                                                   const float* __restrict__ bias, float* __restrict__ out,
                                                                   int64_t op, int B, int C4, int H, int W, int Ho, int Wo,
                                                                   int stride) {
-  const int64_t total = (int64_t)B * Ho * Wo * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4) * 4;
-    int64_t t = i / C4;
-    const int wo = (int)(t % Wo);
+  // the nine window loads are unconditional (a tap outside the map reads a clamped address and is replaced by -inf):
+  // under "if (outside) continue" each one was an exec-masked branch followed by s_waitcnt vmcnt(0) -- nine serialised
+  // memory round trips per output.  32-bit index arithmetic (element count checked by the host).
+  const int total = B * Ho * Wo * C4;
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
+    const int q = (i % C4) * 4;
+    int t = i / C4;
+    const int wo = t % Wo;
     t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int b = (int)(t / Ho);
+    const int ho = t % Ho;
+    const int b = t / Ho;
     const int h0 = ho * stride - 1, w0 = wo * stride - 1;
+    float4 v[9];
+    bool in[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int h = h0 + k / 3, w = w0 + k % 3;
+      in[k] = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+      v[k] = *reinterpret_cast<const float4*>(p + ((int64_t)(b * H + min(max(h, 0), H - 1)) * W + min(max(w, 0), W - 1)) * pp + q);
+    }
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int h = h0 + dy;
-      if (h < 0 || h >= H) continue;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int w = w0 + dx;
-        if (w < 0 || w >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(p + (((int64_t)b * H + h) * W + w) * pp + q);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-      }
+    for (int k = 0; k < 9; ++k) {
+      m.x = fmaxf(m.x, in[k] ? v[k].x : -INFINITY); m.y = fmaxf(m.y, in[k] ? v[k].y : -INFINITY);
+      m.z = fmaxf(m.z, in[k] ? v[k].z : -INFINITY); m.w = fmaxf(m.w, in[k] ? v[k].w : -INFINITY);
     }
     const int64_t o = ((int64_t)b * Ho + ho) * Wo + wo;
     const float4 av = *reinterpret_cast<const float4*>(a + o * ap + q);
@@ -420,6 +424,7 @@ extern "C" int smos_downsample_epilogue_cl(const float* a, int64_t a_pitch, cons
   SMOS_REQUIRE(a && p && bias && out && al16(a) && al16(p) && al16(bias) && al16(out) && a_pitch % 4 == 0 && p_pitch % 4 == 0 &&
                    out_pitch % 4 == 0, "downsample_epilogue_cl: pointers / pitches must be 16-byte aligned");
   const int Ho = (int)((H + 2 - 3) / stride + 1), Wo = (int)((W + 2 - 3) / stride + 1);
+  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < (1LL << 31) && B * H < (1LL << 31), "downsample_epilogue_cl: too many elements for 32-bit indices");
   hipLaunchKernelGGL(downsample_epilogue_cl2, dim3(grid_for(B * Ho * Wo * (C / 4), kBlock, 256 * 16)), dim3(kBlock), 0,
                      (hipStream_t)stream, a, a_pitch, p, p_pitch, bias, out, out_pitch, (int)B, (int)(C / 4), (int)H, (int)W, Ho, Wo,
                      (int)stride);

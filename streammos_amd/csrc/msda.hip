@@ -185,16 +185,21 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_qp_d32(const float* __restric
     const float* vb = value + (b * S) * wstride + (int64_t)m * 32 + lane32;
     float col = 0.f;
     const int half_base = threadIdx.x & 32;
+    // the four taps of a sample are loaded unconditionally and together (an absent tap reads row 0 and enters with weight
+    // 0): as "(o >= 0) ? vb[..] : 0" each load sat under a lane-dependent branch (the two halves of a wave own different
+    // heads) and was followed by s_waitcnt vmcnt(0) -- sixteen serialised round trips per (token, head)
     for (int p = 0; p < P; ++p) {
       const int src = half_base + p;
-      float tap = 0.f;
+      float v[4], w[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int o = __shfl(co[k], src);
-        const float w = __shfl(cw[k], src);
-        const float v = (o >= 0) ? vb[(int64_t)o * wstride] : 0.f;
-        tap += w * v;
+        w[k] = o >= 0 ? __shfl(cw[k], src) : 0.f;
+        v[k] = vb[(int64_t)max(o, 0) * wstride];
       }
+      float tap = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tap += w[k] * v[k];
       col += tap * __shfl(aw, src);
     }
     out[hq * 32 + lane32] = col;
