@@ -29,8 +29,7 @@ for ts, d in ev:
         two_busy += ts - last
     depth += d
     last = ts
-print("# at least one kernel running %.3f ms (idle %.3f ms), at least two %.3f ms  -- under rocprofv3 --kernel-trace the dispatches of "
-      "the two HIP streams are serialised, so the traced wall time is the SUM of the kernels; the untraced step is shorter" %
+print("# at least one kernel running %.3f ms (idle %.3f ms), at least two %.3f ms  -- whether rocprofv3 --kernel-trace serialises the dispatches of the two HIP streams differs from box to box: with \"at least two\" near 0 the wall time is the SUM of the kernels and the untraced step is shorter" %
       (any_busy / 1e6, (t1 - t0 - any_busy) / 1e6, two_busy / 1e6))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%9.1f us  x%3d  %s" % (v[1] / 1e3, v[0], k))

@@ -10,6 +10,10 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 > $OUT/bench_trace.log 2>&1
 echo "trace done"
+# the same with the two pipeline streams folded into one: per-kernel durations without the other stream's kernels on the CUs
+# (whether the tracer serialises the two streams by itself differs from box to box)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-pipeline > $OUT/bench_trace_serial.log 2>&1
+echo "serial trace done"
 PMCARGS="--steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-pipeline"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 -u $R/bench.py $PMCARGS --label-log $OUT/labels.json > $OUT/bench_fetch.log 2>&1
 echo "fetch done"
@@ -24,6 +28,9 @@ python3 $R/profiles/mfma_busy_summary.py $M > $OUT/mfma_busy.txt
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 cp $S $OUT/kernel_stats.csv
 python3 $R/profiles/step_breakdown.py $T > $OUT/step_breakdown.txt 2>&1 || true
+S2=$(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1); T2=$(find $OUT/trace_serial -name "*kernel_trace.csv" | head -1)
+cp $S2 $OUT/kernel_stats_serial.csv
+python3 $R/profiles/step_breakdown.py $T2 > $OUT/step_breakdown_serial.txt 2>&1 || true
 grep "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench_traced.json.log || true
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
+rm -rf $OUT/trace $OUT/trace_serial $OUT/fetch $OUT/write $OUT/mfma
 ls -la $OUT
