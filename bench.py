@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="with --graph: TTA groups replayed concurrently on HIP streams")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the encoder of frame t+1 with the decoder of frame t")
-    ap.add_argument("--cpu-scans", type=int, default=2, help="timed scans of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-scans", type=int, default=4, help="timed scans of the CPU baseline (0 = skip); 4 scans = about 15 s")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
     ap.add_argument("--label-log", default=None,
