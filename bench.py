@@ -153,7 +153,7 @@ def executed_flops(engine, b, n, t, stem_class_rows):
     for L in engine.layers:                                                      # temporal fusion: five linears per layer
         lin = c * c + c * L.qproj[0].shape[0] + c * c + 2 * c * L.lin1[0].shape[0]
         total += 2.0 * b * h2 * w2 * lin
-    c0, cc1, cc2 = engine.conv_1a.shape[1], engine.conv_1z[0].shape[1], engine.conv_1z[1].shape[1]
+    c0, cc1, cc2 = engine.conv_1a.shape[1], engine.conv_1z[0].cin, engine.conv_1z[1].cin
     co = engine.conv_1a.shape[0]
     if engine.upconv:
         total += 2.0 * b * (h0 * w0 * 9 * c0 * co + h1 * w1 * 9 * cc1 * co + h2 * w2 * 9 * cc2 * co)

@@ -562,16 +562,33 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     return out
 
 
+class TapWeights:
+    """The per-tap matrices of a 3x3 convolution's input channels [c0, c1) in the forms upconv3x3 uses.  Everything
+    derived from the weights lives in this object (owned by the engine that folded them) -- never in a cache keyed by
+    the weights' address: a freed model's address is handed to the next model."""
+
+    def __init__(self, w, c0, c1):
+        cout = w.shape[0]
+        self.cout, self.cin = cout, c1 - c0
+        self.nk = w[:, c0:c1].permute(2, 3, 0, 1).reshape(9 * cout, c1 - c0).float().contiguous()   # tap-major, t = 3 ky + kx
+        self.kn = self.nk.t().contiguous()                      # [Cin, 9*Cout]: the layout the library GEMM is fastest in
+        self.zero = torch.zeros(9 * cout, dtype=torch.float32, device=w.device)
+        self._conv = None
+
+    def conv_operand(self):
+        if self._conv is None:
+            self._conv = conv_prepare(self.nk.view(9 * self.cout, self.cin, 1, 1), 4)
+        return self._conv
+
+
 def upconv_tap_weights(w, c0, c1):
-    """w [Cout, Cin, 3, 3] -> [9*Cout, c1-c0]: the per-tap matrices of input channels [c0, c1), tap-major (t = 3 ky + kx)."""
-    cout = w.shape[0]
-    return w[:, c0:c1].permute(2, 3, 0, 1).reshape(9 * cout, c1 - c0).float().contiguous()
+    """w [Cout, Cin, 3, 3] -> TapWeights of input channels [c0, c1)."""
+    return TapWeights(w, c0, c1)
 
 
 # The nine tap products: library GEMM by default; "conv" runs them on the own kernel as one 1x1 convolution with 9*C outputs
 # (measured in the step: 236.6 vs 238.8 scans/s -- K = 128 is only four stages per tile, so the epilogue dominates).
 _TAP_GEMM_OWN = os.environ.get("SMOS_TAP_GEMM", "mm") == "conv"
-_tap_prepared = {}
 
 
 def upconv3x3(conv_a, bias, sources, act, out=None):
@@ -588,22 +605,16 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
     with torch.cuda.device(conv_a.device):
         for x, wt in sources:
             hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
+            if wt.cin != cin or wt.cout != c:
+                raise RuntimeError("upconv3x3: tap weights are for %d -> %d channels, got %d -> %d" % (wt.cin, wt.cout, cin, c))
             if _TAP_GEMM_OWN and cin % 32 == 0 and (9 * c) % 128 == 0:
-                key = (wt.data_ptr(), wt._version)
-                wp = _tap_prepared.get(key)
-                if wp is None:
-                    wp = _tap_prepared[key] = conv_prepare(wt.view(9 * c, cin, 1, 1), 4)
-                z = conv_cl(x, wp, None, 0, 9 * c, (1, 1), mt=4)
+                z = conv_cl(x, wt.conv_operand(), None, 0, 9 * c, (1, 1), mt=4)
             else:
                 rows = x.permute(0, 2, 3, 1).reshape(b * hs * ws, cin)     # no copy for a dense channels-last map
                 # [B*Hs*Ws, 9*C]: the nine tap products.  addmm with a zero bias on the [Cin, 9*C] copy of the weights:
-                # the library picks a faster kernel for this form than for mm(rows, wt.t()) (tools/ubench_tapgemm.py:
+                # the library picks a faster kernel for this form than for mm(rows, nk.t()) (tools/ubench_tapgemm.py:
                 # 0.182 vs 0.207 ms at 65536 x 128 x 1152); adding 0 changes no value
-                key = (wt.data_ptr(), wt._version, "kn")
-                kn = _tap_prepared.get(key)
-                if kn is None:
-                    kn = _tap_prepared[key] = (wt.t().contiguous(), torch.zeros(wt.shape[0], dtype=wt.dtype, device=wt.device))
-                z = torch.addmm(kn[1], rows, kn[0])
+                z = torch.addmm(wt.zero, rows, wt.kn)
             t = torch.empty((b, 3, hs, wo, c), dtype=torch.float32, device=conv_a.device)
             with profiling.span("upconv_xpass[%dx%dx%dx%d->%d]" % (b, hs, ws, c, wo)):
                 _lib.check(lib.smos_upconv_xpass(z.data_ptr(), t.data_ptr(), b, hs, ws, c, wo, st), "smos_upconv_xpass")

@@ -309,6 +309,16 @@ def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes):
     srcs = [(x, ops.upconv_tap_weights(w, c0 + i * cs, c0 + (i + 1) * cs)) for i, x in enumerate(xs)]
     got = ops.upconv3x3(conv_a, bias, srcs, 2)
     assert (got.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    # other weights at (very likely) the same addresses: nothing derived from the first set may survive in a cache
+    # keyed by a weight's address (a freed model's memory is handed to the next model by the caching allocator)
+    ptr = w.data_ptr()
+    del srcs, w
+    w = (torch.randn((cout, cin, 3, 3), generator=gen) * 0.1).to(DEV)
+    want2 = F.leaky_relu(F.conv2d(torch.cat([x0.double()] + ups, 1), w.double(), bias.double(), 1, 1), 0.01)
+    conv_a = F.conv2d(x0, w[:, :c0].contiguous(memory_format=torch.channels_last), None, 1, 1)
+    srcs = [(x, ops.upconv_tap_weights(w, c0 + i * cs, c0 + (i + 1) * cs)) for i, x in enumerate(xs)]
+    got2 = ops.upconv3x3(conv_a, bias, srcs, 2)
+    assert (got2.double() - want2).abs().max().item() <= 2e-5 * want2.abs().max().item(), (ptr == w.data_ptr())
 
 
 @pytest.mark.parametrize("hw,m,pnt", [((64, 64), 4, 4), ((20, 36), 2, 8), ((7, 5), 4, 3)])
