@@ -460,18 +460,64 @@ def point_head(rows, wprep, m3, out=None):
     return out
 
 
-def conv_prepare(w, mt):
+def conv_prepare(w, mt, order="taps"):
     """w [Cout, Cin, KH, KW] (BatchNorm folded) -> the weight block of smos_conv_cl in MFMA operand order for `mt`
     32-channel output blocks per wave (include/smos.h): [cout tile][stage = (ky, kx, cin chunk)][k-step / 4][mt][lane][k-step % 4]
-    with lane = h * 32 + m holding w[ct*32*mt + mt_i*32 + m][chunk*32 + 8*i4 + 4*h + c][ky][kx]."""
+    with lane = h * 32 + m holding w[ct*32*mt + mt_i*32 + m][chunk*32 + 8*i4 + 4*h + c][ky][kx].
+    order="rows" (smos_conv_rows_cl, mt = 1): stage = (ky, cin chunk, kx) -- the kx taps of a staged input row together."""
     cout, cin, kh, kw = w.shape
-    if cin % 32 or cout % (32 * mt) or mt not in (1, 2, 4):
-        raise RuntimeError("conv_prepare: Cin %% 32 == 0 and Cout %% (32 * mt) == 0 required (got %s, mt=%d)" % (tuple(w.shape), mt))
+    if cin % 32 or cout % (32 * mt) or mt not in (1, 2, 4) or order not in ("taps", "rows") or (order == "rows" and mt != 1):
+        raise RuntimeError("conv_prepare: Cin %% 32 == 0 and Cout %% (32 * mt) == 0 required (got %s, mt=%d, order=%s)" % (tuple(w.shape), mt, order))
     #           ct                mt_i  m   chunk      i4  h  c   ky  kx
     v = w.float().reshape(cout // (32 * mt), mt, 32, cin // 32, 4, 2, 4, kh, kw)
-    #  -> [ct, ky, kx, chunk, i4, mt_i, h, m, c]
-    v = v.permute(0, 7, 8, 3, 4, 1, 5, 2, 6)
+    if order == "rows":
+        v = v.permute(0, 7, 3, 8, 4, 1, 5, 2, 6)     # -> [ct, ky, chunk, kx, i4, mt_i, h, m, c]
+    else:
+        v = v.permute(0, 7, 8, 3, 4, 1, 5, 2, 6)     # -> [ct, ky, kx, chunk, i4, mt_i, h, m, c]
     return v.reshape(-1).contiguous()
+
+
+def conv_rows_ok(kernel, stride, cin, cout):
+    """Shapes smos_conv_rows_cl covers (stride 1, "same" padding, KW in {3, 5, 7})."""
+    kh, kw = kernel
+    return stride == 1 and kw in (3, 5, 7) and kh in (1, 3, 5, 7) and cin % 32 == 0 and cout % 32 == 0
+
+
+def conv_rows_cl(x, wprep, bias, act, cout, kernel, residual=None, out=None, chan_sums=None):
+    """conv_cl for stride 1 / "same" padding / KW in {3, 5, 7} at 32 output channels per block, with the input rows staged
+    through LDS once per kernel row instead of one global request per tap (csrc/conv_rows.hip).
+    wprep = conv_prepare(w, 1, order="rows")."""
+    _require_cuda("conv_rows_cl", x, wprep, bias, residual, out, chan_sums)
+    b, cin, h, w = x.shape
+    kh, kw = kernel
+    if not conv_rows_ok(kernel, 1, cin, cout) or wprep.numel() != cout * cin * kh * kw:
+        raise RuntimeError("conv_rows_cl: unsupported shape %s k%dx%d -> %d" % (tuple(x.shape), kh, kw, cout))
+    if out is None:
+        out = empty_cl(b, cout, h, w, x.device)
+    elif tuple(out.shape) != (b, cout, h, w):
+        raise RuntimeError("conv_rows_cl: out has shape %s" % (tuple(out.shape),))
+    if residual is not None and tuple(residual.shape) != (b, cout, h, w):
+        raise RuntimeError("conv_rows_cl: residual has shape %s" % (tuple(residual.shape),))
+    if chan_sums is not None and (residual is not None or not chan_sums.is_contiguous() or
+                                  tuple(chan_sums.shape) != (b, conv_sum_chunks(h, w), cout)):
+        raise RuntimeError("conv_rows_cl: chan_sums must be contiguous [B, conv_sum_chunks(H, W), Cout], without a residual")
+    lib = _lib.load()
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, h, w, kh, kw, "+res" if residual is not None else "")
+    args = (x.data_ptr(), _cl("conv_rows_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None, _cl("conv_rows_cl", residual) if residual is not None else 0,
+            out.data_ptr(), _cl("conv_rows_cl", out), b, h, w, cin, cout, kh, kw, int(act),
+            chan_sums.data_ptr() if chan_sums is not None else None)
+    with torch.cuda.device(x.device), profiling.span(label):
+        rc = lib.smos_conv_rows_cl(*args, _stream(x))
+    _lib.check(rc, "smos_conv_rows_cl")
+    if profiling._replay_label == label:
+        keep = (x, wprep, bias, residual, out, chan_sums)
+
+        def again(keep=keep):
+            with torch.cuda.device(keep[0].device), profiling.span(label):
+                _lib.check(lib.smos_conv_rows_cl(*args, _stream(keep[0])), "smos_conv_rows_cl")
+        profiling.offer_replay(label, again)
+    return out
 
 
 _CONV_MIN_WAVE_TILES = int(os.environ.get("SMOS_CONV_MIN_WAVE_TILES", "2048"))   # tuning knob (tools/ubench_conv.py)
