@@ -16,7 +16,7 @@ import json
 import sys
 
 # kernel-name fragment -> label prefix, for the kernels that carry a one-launch profiling span in ops.py
-KIND = (("conv_igemm", "conv_cl["), ("gather_scatter_cl", "gather_scatter_cl["), ("pointnet_scatter", "pointnet_scatter["),
+KIND = ((("conv_igemm", "conv_rows"), "conv_cl["), ("gather_scatter_cl", "gather_scatter_cl["), ("pointnet_scatter", "pointnet_scatter["),
         ("point_head", "point_head["), ("stem_gemm", "stem_gemm["), ("stem_epilogue", "stem_epilogue["))
 LABELS = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else []
 
@@ -33,7 +33,8 @@ def per_label(path, counter):
     out = collections.defaultdict(list)
     for frag, prefix in KIND:
         want = [l for l in LABELS if l.startswith(prefix)]
-        have = [r for r in step if frag in r["Kernel_Name"]]
+        frags = frag if isinstance(frag, tuple) else (frag,)
+        have = [r for r in step if any(f in r["Kernel_Name"] for f in frags)]
         if len(want) != len(have):
             sys.stderr.write("pmc_summary: %d dispatches of %s vs %d labels -- skipped\n" % (len(have), frag, len(want)))
             continue
