@@ -261,14 +261,15 @@ int smos_add_layer_norm(const float* x, const float* res, const float* gamma, co
  *   x / 32) * 4 + y % 4; segments outside the image hold 0): the global-average-pool input of a ChannelAtt block
  *   (networks/backbone.py:57-73) without another pass over the map.  Summation order is fixed (run-to-run identical). */
 int64_t smos_conv_cl_sum_chunks(int64_t Ho, int64_t Wo);
-/* smos_conv_cl for stride 1, "same" padding (pad = K / 2), KW in {3, 5, 7}, odd KH <= 7, 32 output channels per block, with
- * the input rows staged through LDS once per kernel row and 32-channel chunk (csrc/conv_rows.hip): one coalesced request per
- * row instead of one per tap.  Same operands and epilogue; the weight block is ordered (ky, cin chunk, kx) inside a tile:
- *   wprep[(((ct * KH + ky) * (Cin / 32) + cc) * KW + kx) * 4 + i4][lane][c]
- *       = w[ct * 32 + (lane & 31)][cc * 32 + 8 * i4 + 4 * (lane >> 5) + c][ky][kx]. */
+/* smos_conv_cl for stride 1, "same" padding (pad = K / 2), KW in {3, 5, 7}, odd KH <= 7, mt in {1, 2} (32 / 64 output
+ * channels per block), with the input rows staged through LDS once per kernel row and 32-channel chunk
+ * (csrc/conv_rows.hip): one coalesced request per row instead of one per tap.  Same operands and epilogue; the weight block
+ * is ordered (ky, cin chunk, kx) inside a tile:
+ *   wprep[((((ct * KH + ky) * (Cin / 32) + cc) * KW + kx) * 4 + i4) * mt + m][lane][c]
+ *       = w[ct * 32 * mt + m * 32 + (lane & 31)][cc * 32 + 8 * i4 + 4 * (lane >> 5) + c][ky][kx]. */
 int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
                       float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t KH,
-                      int32_t KW, int32_t act, float* chan_sums, smos_stream_t stream);
+                      int32_t KW, int32_t mt, int32_t act, float* chan_sums, smos_stream_t stream);
 int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
                  float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t KH,
                  int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt, int32_t act, float* chan_sums,

@@ -1,4 +1,4 @@
-// Stride-1 channels-last fp32 convolution with KW in {3, 5, 7} and 32 output channels per block: the same implicit GEMM as
+// Stride-1 channels-last fp32 convolution with KW in {3, 5, 7} and 32 or 64 output channels per block: the same implicit GEMM as
 // csrc/conv_igemm.hip (transposed form, streamed weight ring, fused epilogue) with a different ACTIVATION path.
 //
 // conv_igemm requests the B operand of every stage straight from global memory: lane (p, h) = pixel p, 16 bytes per load,
@@ -20,10 +20,10 @@
 
 namespace smos {
 
-template <int KW, bool RES, bool SUMS>
+template <int KW, int MT, bool RES, bool SUMS>
 __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 float4 | bias | 4 waves x 2 row buffers
-  constexpr int kSlot = 256;
+  extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 * MT float4 | bias | 4 waves x 2 row buffers
+  constexpr int kSlot = 256 * MT;
   constexpr int kWt = 32 + KW - 1;                  // pixels of a staged row
   constexpr int kNL = (kWt * 8 + 63) / 64;          // float4 per lane of a staged row
   constexpr int kPitch = 36;                        // floats per pixel in LDS
@@ -121,35 +121,49 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
   // ---- weight requests (three stages ahead), as in conv_igemm ----
   const int n_slices = a.nct * a.nstage;
   int pa_slice = (first % a.nct) * a.nstage, pa_g = 0;
-  auto load_a = [&](float4& r0) {
-    r0 = a.w[(int64_t)(pa_g < total ? pa_slice : 0) * kSlot + tid];
+  auto load_a = [&](float4& r0, float4& r1) {      // named registers: an array here ends up in scratch for MT > 1
+    const float4* wsrc = a.w + (int64_t)(pa_g < total ? pa_slice : 0) * kSlot + tid;
+    r0 = wsrc[0];
+    if constexpr (MT > 1) r1 = wsrc[256];
     ++pa_g;
     pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;
   };
   float4* ring_tid = ring + tid;
   const float4* ring_lane = ring + lane;
-  auto park = [&](int slot, const float4& r0) { ring_tid[slot * kSlot] = r0; };
-  auto read_a = [&](float4 (&af)[4], int slot, int i4) { af[i4] = ring_lane[slot * kSlot + i4 * 64]; };
-
-  f32x16 acc;
+  auto park = [&](int slot, const float4& r0, const float4& r1) {
+    ring_tid[slot * kSlot] = r0;
+    if constexpr (MT > 1) ring_tid[slot * kSlot + 256] = r1;
+  };
+  auto read_a = [&](float4 (&af)[4][MT], int slot, int i4) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  auto mfma_half = [&](const float4 (&af)[4], const float4& bv, int i4, bool lo) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4].x : af[i4].z, lo ? bv.x : bv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4].y : af[i4].w, lo ? bv.y : bv.w, acc, 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt) af[i4][mt] = ring_lane[slot * kSlot + (i4 * MT + mt) * 64];
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+  auto mfma_half = [&](const float4 (&af)[4][MT], const float4& bv, int i4, bool lo) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4][mt].x : af[i4][mt].z, lo ? bv.x : bv.z, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4][mt].y : af[i4][mt].w, lo ? bv.y : bv.w, acc[mt], 0, 0, 0);
   };
 
   int c_it = 0, c_left = a.nstage;
-  u32x4 rr[RES ? 4 : 1];
+  u32x4 rr[RES ? 4 * MT : 1];
   auto request_residual = [&]() {
     if constexpr (RES) {
       const ConvTile t = tile_of(c_it);
       const int x = t.x0 + p;
       const bool want = t.valid & (x < a.Wo);
       const int pix = (t.b * a.Ho + t.y) * a.Wo + x;
-      const unsigned roff = want ? (unsigned)(pix * (int)a.rp + t.ct * 32 + 4 * h) * 4u : 0x80000000u;
+      const unsigned roff = want ? (unsigned)(pix * (int)a.rp + t.ct * 32 * MT + 4 * h) * 4u : 0x80000000u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, roff + 32u * k, 0, 0);
+      for (int k = 0; k < 4 * MT; ++k) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, roff + 32u * k, 0, 0);
     }
   };
   auto epilogue = [&]() {
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
     const int x = t.x0 + p;
     const bool store = t.valid & (x < a.Wo);
     const int pix = (t.b * a.Ho + t.y) * a.Wo + x;
-    const int cbase = t.ct * 32 + 4 * h;
+    const int cbase = t.ct * 32 * MT + 4 * h;
     const unsigned ooff = store ? (unsigned)(pix * (int)a.op + cbase) * 4u : 0x80000000u;
     float* srow = nullptr;
     if constexpr (SUMS) {
@@ -165,41 +179,44 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
       srow = a.sums + ((int64_t)t.b * (a.hq * a.xt * 4) + chunk) * a.cout + cbase;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4*>(bias_lds + cbase + 8 * g);
-      const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-      float o[4];
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = acc[4 * g + c] + bb[c];
-        if constexpr (RES) v += __uint_as_float(rr[g][c]);
-        o[c] = __builtin_fmaf(a.slope, fminf(v, 0.f), fmaxf(v, 0.f));
-        acc[4 * g + c] = 0.0f;
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_lds + cbase + mt * 32 + 8 * g);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = acc[mt][4 * g + c] + bb[c];
+          if constexpr (RES) v += __uint_as_float(rr[4 * mt + g][c]);
+          o[c] = __builtin_fmaf(a.slope, fminf(v, 0.f), fmaxf(v, 0.f));
+          acc[mt][4 * g + c] = 0.0f;
+        }
+        if constexpr (SUMS) {
+          float4 sv;
+          sv.x = half_wave_sum(store ? o[0] : 0.f);
+          sv.y = half_wave_sum(store ? o[1] : 0.f);
+          sv.z = half_wave_sum(store ? o[2] : 0.f);
+          sv.w = half_wave_sum(store ? o[3] : 0.f);
+          if (p == 31) *reinterpret_cast<float4*>(srow + mt * 32 + 8 * g) = sv;
+        }
+        u32x4 ov;
+        ov.x = __float_as_uint(o[0]); ov.y = __float_as_uint(o[1]); ov.z = __float_as_uint(o[2]); ov.w = __float_as_uint(o[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff + 4u * (mt * 32 + 8 * g), 0, 0);
       }
-      if constexpr (SUMS) {
-        float4 sv;
-        sv.x = half_wave_sum(store ? o[0] : 0.f);
-        sv.y = half_wave_sum(store ? o[1] : 0.f);
-        sv.z = half_wave_sum(store ? o[2] : 0.f);
-        sv.w = half_wave_sum(store ? o[3] : 0.f);
-        if (p == 31) *reinterpret_cast<float4*>(srow + 8 * g) = sv;
-      }
-      u32x4 ov;
-      ov.x = __float_as_uint(o[0]); ov.y = __float_as_uint(o[1]); ov.z = __float_as_uint(o[2]); ov.w = __float_as_uint(o[3]);
-      __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff + 4u * (8 * g), 0, 0);
     }
   };
 
-  float4 bA[4], bB[4], af[4];
-  float4 ae0, ao0;      // weight slices of odd / even stages on their way to the ring (stage g parks slice g + 1)
+  float4 bA[4], bB[4], af[4][MT];
+  float4 ae0, ae1, ao0, ao1;      // weight slices of odd / even stages on their way to the ring (stage g parks slice g + 1)
   // ---- prologue: row of group 0 staged, weight slice 0 in the ring, slices 1 and 2 in registers ----
-  load_a(ae0);
+  load_a(ae0, ae1);
   fill_request();                       // group 0
   fill_advance();
-  park(0, ae0);
+  park(0, ae0, ae1);
   fill_write(0);
-  load_a(ao0);
-  load_a(ae0);
+  load_a(ao0, ao1);
+  load_a(ae0, ae1);
   if (RES && c_left == 1) request_residual();
 #pragma unroll
   for (int k = 0; k < 8; ++k)
@@ -215,16 +232,16 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
   //   | [last stage: write that row to the other buffer] | next stage's activations | barrier, fragments 0, 1 of the next
   //   stage | rare: end of a tile
   int g = 0;                            // stage counter (ring slot = g & 3)
-#define SMOS_RSTAGE(KX, bc, bn, n0, buf)                                        \
+#define SMOS_RSTAGE(KX, bc, bn, n0, n1, buf)                                        \
   do {                                                                          \
     const int sc_ = g & 3, sn_ = (g + 1) & 3;                                   \
     mfma_half(af, bc[0], 0, true);                                              \
     SMOS_FENCE();                                                               \
-    park(sn_, n0);                                                              \
+    park(sn_, n0, n1);                                                          \
     SMOS_FENCE();                                                               \
     mfma_half(af, bc[0], 0, false);                                             \
     SMOS_FENCE();                                                               \
-    load_a(n0);                                                                 \
+    load_a(n0, n1);                                                             \
     SMOS_FENCE();                                                               \
     mfma_half(af, bc[1], 1, true);                                              \
     SMOS_FENCE();                                                               \
@@ -267,30 +284,30 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
   // a group of KW stages starting at an even (E) or odd (O) stage: register sets alternate with the stage parity
 #define SMOS_RGROUP_E(buf)                                       \
   do {                                                           \
-    SMOS_RSTAGE(0, bA, bB, ao0, buf);                            \
-    SMOS_RSTAGE(1, bB, bA, ae0, buf);                            \
-    SMOS_RSTAGE(2, bA, bB, ao0, buf);                            \
+    SMOS_RSTAGE(0, bA, bB, ao0, ao1, buf);                            \
+    SMOS_RSTAGE(1, bB, bA, ae0, ae1, buf);                            \
+    SMOS_RSTAGE(2, bA, bB, ao0, ao1, buf);                            \
     if constexpr (KW > 3) {                                      \
-      SMOS_RSTAGE(3, bB, bA, ae0, buf);                          \
-      SMOS_RSTAGE(4, bA, bB, ao0, buf);                          \
+      SMOS_RSTAGE(3, bB, bA, ae0, ae1, buf);                          \
+      SMOS_RSTAGE(4, bA, bB, ao0, ao1, buf);                          \
     }                                                            \
     if constexpr (KW > 5) {                                      \
-      SMOS_RSTAGE(5, bB, bA, ae0, buf);                          \
-      SMOS_RSTAGE(6, bA, bB, ao0, buf);                          \
+      SMOS_RSTAGE(5, bB, bA, ae0, ae1, buf);                          \
+      SMOS_RSTAGE(6, bA, bB, ao0, ao1, buf);                          \
     }                                                            \
   } while (0)
 #define SMOS_RGROUP_O(buf)                                       \
   do {                                                           \
-    SMOS_RSTAGE(0, bB, bA, ae0, buf);                            \
-    SMOS_RSTAGE(1, bA, bB, ao0, buf);                            \
-    SMOS_RSTAGE(2, bB, bA, ae0, buf);                            \
+    SMOS_RSTAGE(0, bB, bA, ae0, ae1, buf);                            \
+    SMOS_RSTAGE(1, bA, bB, ao0, ao1, buf);                            \
+    SMOS_RSTAGE(2, bB, bA, ae0, ae1, buf);                            \
     if constexpr (KW > 3) {                                      \
-      SMOS_RSTAGE(3, bA, bB, ao0, buf);                          \
-      SMOS_RSTAGE(4, bB, bA, ae0, buf);                          \
+      SMOS_RSTAGE(3, bA, bB, ao0, ao1, buf);                          \
+      SMOS_RSTAGE(4, bB, bA, ae0, ae1, buf);                          \
     }                                                            \
     if constexpr (KW > 5) {                                      \
-      SMOS_RSTAGE(5, bA, bB, ao0, buf);                          \
-      SMOS_RSTAGE(6, bB, bA, ae0, buf);                          \
+      SMOS_RSTAGE(5, bA, bB, ao0, ao1, buf);                          \
+      SMOS_RSTAGE(6, bB, bA, ae0, ae1, buf);                          \
     }                                                            \
   } while (0)
 
@@ -312,27 +329,28 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
 
 using namespace smos;
 
-template <int KW, bool RES, bool SUMS>
+template <int KW, int MT, bool RES, bool SUMS>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
   const size_t rows = (size_t)4 * 2 * (32 + KW - 1) * 36 * sizeof(float);
-  const size_t lds = (size_t)4 * 256 * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float) + rows;
+  const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float) + rows;
   KernelSetup ks;
-  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_rows<KW, RES, SUMS>), 4 * 256 * sizeof(float4) + 8192 + rows, 256, &ks, "conv_rows_cl"))
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_rows<KW, MT, RES, SUMS>), 4 * 256 * MT * sizeof(float4) + 8192 + rows, 256, &ks, "conv_rows_cl"))
     return rc;
   const int per_cu = ks.per_cu < 2 ? ks.per_cu : 2;
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
-  hipLaunchKernelGGL((conv_rows<KW, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_rows<KW, MT, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_rows_cl");
 }
 
-// Same contract as smos_conv_cl with stride 1, "same" padding, KW in {3, 5, 7} and mt = 1, except for the weight order:
-// wprep[(((ct * KH + ky) * (Cin / 32) + cc) * KW + kx) * 4 + i4][lane][c] (ops.conv_prepare(..., order="rows")).
+// Same contract as smos_conv_cl with stride 1, "same" padding, KW in {3, 5, 7} and mt in {1, 2}, except for the weight
+// order: wprep[((((ct * KH + ky) * (Cin / 32) + cc) * KW + kx) * 4 + i4) * mt + m][lane][c] (ops.conv_prepare(..., order="rows")).
 extern "C" int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res,
                                  int64_t res_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin,
-                                 int64_t Cout, int32_t KH, int32_t KW, int32_t act, float* chan_sums, smos_stream_t stream) {
-  SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0 && Cout <= 2048,
-               "conv_rows_cl: Cin and Cout must be multiples of 32 (Cout <= 2048)");
+                                 int64_t Cout, int32_t KH, int32_t KW, int32_t mt, int32_t act, float* chan_sums,
+                                 smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && (mt == 1 || mt == 2) && Cout % (32 * mt) == 0 &&
+                   Cout <= 2048, "conv_rows_cl: Cin a multiple of 32, Cout of 32 * mt (mt in {1, 2}; Cout <= 2048)");
   SMOS_REQUIRE(KH >= 1 && KH <= 7 && (KH & 1) && (KW == 3 || KW == 5 || KW == 7) && act >= 0 && act <= 2,
                "conv_rows_cl: odd KH <= 7, KW in {3, 5, 7}");
   SMOS_REQUIRE(x && wprep && out && x_pitch >= Cin && out_pitch >= Cout && x_pitch % 4 == 0 && out_pitch % 4 == 0 &&
@@ -340,7 +358,7 @@ extern "C" int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* w
   SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
                  reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(wprep) | reinterpret_cast<uintptr_t>(chan_sums)) & 15) == 0,
                "conv_rows_cl: pointers must be 16-byte aligned");
-  const int64_t hq = (H + 3) / 4, xt = (W + 31) / 32, nct = Cout / 32;
+  const int64_t hq = (H + 3) / 4, xt = (W + 31) / 32, nct = Cout / (32 * mt);
   SMOS_REQUIRE(B * H * W * x_pitch * 4 < (1LL << 31) && B * H * W * out_pitch * 4 < (1LL << 31) &&
                    (!res || B * H * W * res_pitch * 4 < (1LL << 31)), "conv_rows_cl: a tensor larger than 2 GiB (32-bit buffer offsets)");
   SMOS_REQUIRE(B * hq * xt * nct < (1LL << 30) && (int64_t)KH * KW * (Cin / 32) * nct < (1LL << 20), "conv_rows_cl: too many tiles");
@@ -360,11 +378,16 @@ extern "C" int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* w
   a.o_bytes = (int)(B * H * W * out_pitch * 4);
   a.cout = (int)Cout;
   hipStream_t s = (hipStream_t)stream;
-#define SMOS_ROWS_DISPATCH(KW_)                                          \
-  if (KW == KW_) {                                                       \
-    if (chan_sums) return launch_rows<KW_, false, true>(a, s);           \
-    if (res) return launch_rows<KW_, true, false>(a, s);                 \
-    return launch_rows<KW_, false, false>(a, s);                         \
+#define SMOS_ROWS_DISPATCH(KW_)                                                                  \
+  if (KW == KW_) {                                                                               \
+    if (mt == 1) {                                                                               \
+      if (chan_sums) return launch_rows<KW_, 1, false, true>(a, s);                              \
+      if (res) return launch_rows<KW_, 1, true, false>(a, s);                                    \
+      return launch_rows<KW_, 1, false, false>(a, s);                                            \
+    }                                                                                            \
+    if (chan_sums) return launch_rows<KW_, 2, false, true>(a, s);                                \
+    if (res) return launch_rows<KW_, 2, true, false>(a, s);                                      \
+    return launch_rows<KW_, 2, false, false>(a, s);                                              \
   }
   SMOS_ROWS_DISPATCH(3)
   SMOS_ROWS_DISPATCH(5)

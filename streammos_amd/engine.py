@@ -151,6 +151,7 @@ class InferenceEngine:
         # epilogue fused (csrc/conv_igemm.hip).  SMOS_OWN_CONV=0 falls back to MIOpen convs + separate epilogue passes
         # (kept for A/B runs; tools/ubench_conv.py compares the two per layer).
         self.own_conv = os.environ.get("SMOS_OWN_CONV", "1") != "0"
+        self.conv_rows_mt = int(os.environ.get("SMOS_CONV_ROWS_MT", "1"))      # largest mt the row-staging conv is used for
         self.conv_rows = int(os.environ.get("SMOS_CONV_ROWS", "3"))      # n > 0: row-staging conv for KW >= n at mt = 1; 0: off
         self.fused_gate_sums = os.environ.get("SMOS_GATE_SUMS", "1") != "0"      # ChannelAtt pool sums from the conv epilogue
         self._wprep = {}
@@ -373,14 +374,14 @@ class InferenceEngine:
         b, _, h, wd = x.shape
         ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (wd + 2 * (kw // 2) - kw) // stride + 1
         mt = ops.conv_mt(cout, b * ho * wo, residual is not None)
-        if self.conv_rows and mt == 1 and ops.conv_rows_ok((kh, kw), stride, cin, cout) and kw >= self.conv_rows:
+        if self.conv_rows and mt <= self.conv_rows_mt and ops.conv_rows_ok((kh, kw), stride, cin, cout) and kw >= self.conv_rows:
             # the row-staging variant (csrc/conv_rows.hip): per layer within 0 .. -5 % of conv_igemm alone on the GPU, +1 % in the
             # two-stream step (241.9 vs 239.1 scans/s: a fifth of the L1 requests leaves more of the memory path to the other stream)
-            key = (w.data_ptr(), "rows")
+            key = (w.data_ptr(), "rows", mt)
             wp = self._wprep.get(key)
             if wp is None:
-                wp = self._wprep[key] = ops.conv_prepare(w, 1, order="rows")
-            return ops.conv_rows_cl(x, wp, bias, act, cout, (kh, kw), residual=residual, out=out, chan_sums=chan_sums)
+                wp = self._wprep[key] = ops.conv_prepare(w, mt, order="rows")
+            return ops.conv_rows_cl(x, wp, bias, act, cout, (kh, kw), mt=mt, residual=residual, out=out, chan_sums=chan_sums)
         key = (w.data_ptr(), mt)
         wp = self._wprep.get(key)
         if wp is None:

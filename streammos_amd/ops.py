@@ -464,9 +464,9 @@ def conv_prepare(w, mt, order="taps"):
     """w [Cout, Cin, KH, KW] (BatchNorm folded) -> the weight block of smos_conv_cl in MFMA operand order for `mt`
     32-channel output blocks per wave (include/smos.h): [cout tile][stage = (ky, kx, cin chunk)][k-step / 4][mt][lane][k-step % 4]
     with lane = h * 32 + m holding w[ct*32*mt + mt_i*32 + m][chunk*32 + 8*i4 + 4*h + c][ky][kx].
-    order="rows" (smos_conv_rows_cl, mt = 1): stage = (ky, cin chunk, kx) -- the kx taps of a staged input row together."""
+    order="rows" (smos_conv_rows_cl, mt <= 2): stage = (ky, cin chunk, kx) -- the kx taps of a staged input row together."""
     cout, cin, kh, kw = w.shape
-    if cin % 32 or cout % (32 * mt) or mt not in (1, 2, 4) or order not in ("taps", "rows") or (order == "rows" and mt != 1):
+    if cin % 32 or cout % (32 * mt) or mt not in (1, 2, 4) or order not in ("taps", "rows") or (order == "rows" and mt > 2):
         raise RuntimeError("conv_prepare: Cin %% 32 == 0 and Cout %% (32 * mt) == 0 required (got %s, mt=%d, order=%s)" % (tuple(w.shape), mt, order))
     #           ct                mt_i  m   chunk      i4  h  c   ky  kx
     v = w.float().reshape(cout // (32 * mt), mt, 32, cin // 32, 4, 2, 4, kh, kw)
@@ -483,14 +483,14 @@ def conv_rows_ok(kernel, stride, cin, cout):
     return stride == 1 and kw in (3, 5, 7) and kh in (1, 3, 5, 7) and cin % 32 == 0 and cout % 32 == 0
 
 
-def conv_rows_cl(x, wprep, bias, act, cout, kernel, residual=None, out=None, chan_sums=None):
-    """conv_cl for stride 1 / "same" padding / KW in {3, 5, 7} at 32 output channels per block, with the input rows staged
-    through LDS once per kernel row instead of one global request per tap (csrc/conv_rows.hip).
-    wprep = conv_prepare(w, 1, order="rows")."""
+def conv_rows_cl(x, wprep, bias, act, cout, kernel, mt=1, residual=None, out=None, chan_sums=None):
+    """conv_cl for stride 1 / "same" padding / KW in {3, 5, 7} at 32 * mt (mt in {1, 2}) output channels per block, with the
+    input rows staged through LDS once per kernel row instead of one global request per tap (csrc/conv_rows.hip).
+    wprep = conv_prepare(w, mt, order="rows")."""
     _require_cuda("conv_rows_cl", x, wprep, bias, residual, out, chan_sums)
     b, cin, h, w = x.shape
     kh, kw = kernel
-    if not conv_rows_ok(kernel, 1, cin, cout) or wprep.numel() != cout * cin * kh * kw:
+    if not conv_rows_ok(kernel, 1, cin, cout) or wprep.numel() != cout * cin * kh * kw or mt not in (1, 2) or cout % (32 * mt):
         raise RuntimeError("conv_rows_cl: unsupported shape %s k%dx%d -> %d" % (tuple(x.shape), kh, kw, cout))
     if out is None:
         out = empty_cl(b, cout, h, w, x.device)
@@ -505,7 +505,7 @@ def conv_rows_cl(x, wprep, bias, act, cout, kernel, residual=None, out=None, cha
     label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, h, w, kh, kw, "+res" if residual is not None else "")
     args = (x.data_ptr(), _cl("conv_rows_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             residual.data_ptr() if residual is not None else None, _cl("conv_rows_cl", residual) if residual is not None else 0,
-            out.data_ptr(), _cl("conv_rows_cl", out), b, h, w, cin, cout, kh, kw, int(act),
+            out.data_ptr(), _cl("conv_rows_cl", out), b, h, w, cin, cout, kh, kw, int(mt), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
     with torch.cuda.device(x.device), profiling.span(label):
         rc = lib.smos_conv_rows_cl(*args, _stream(x))

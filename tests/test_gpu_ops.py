@@ -703,23 +703,27 @@ def test_conv_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mt):
 
 
 _ROWS_CASES = [
-    # cin, cout, (kh, kw), (h, w), act, residual, sums
-    (32, 32, (3, 3), (40, 64), 1, False, False),
-    (32, 32, (7, 3), (20, 64), 1, False, False),
-    (32, 32, (3, 7), (20, 64), 1, False, False),
-    (64, 32, (3, 3), (24, 96), 1, True, False),
-    (64, 64, (5, 3), (24, 32), 1, False, False),
-    (64, 64, (3, 5), (24, 32), 2, False, False),
-    (128, 128, (3, 3), (16, 32), 1, True, False),
-    (128, 64, (3, 3), (16, 64), 0, False, True),
-    (32, 32, (3, 3), (13, 45), 2, True, False),          # partial tiles in both directions
-    (32, 64, (3, 3), (3, 8), 1, False, True),            # smaller than one tile
-    (32, 32, (1, 3), (9, 70), 0, False, False),
+    # cin, cout, (kh, kw), (h, w), act, residual, sums, mt
+    (32, 32, (3, 3), (40, 64), 1, False, False, 1),
+    (32, 32, (7, 3), (20, 64), 1, False, False, 1),
+    (32, 32, (3, 7), (20, 64), 1, False, False, 1),
+    (64, 32, (3, 3), (24, 96), 1, True, False, 1),
+    (64, 64, (5, 3), (24, 32), 1, False, False, 1),
+    (64, 64, (3, 5), (24, 32), 2, False, False, 1),
+    (128, 128, (3, 3), (16, 32), 1, True, False, 1),
+    (128, 64, (3, 3), (16, 64), 0, False, True, 1),
+    (32, 32, (3, 3), (13, 45), 2, True, False, 1),          # partial tiles in both directions
+    (32, 64, (3, 3), (3, 8), 1, False, True, 1),            # smaller than one tile
+    (32, 32, (1, 3), (9, 70), 0, False, False, 1),
+    (64, 64, (3, 3), (24, 40), 1, False, False, 2),
+    (128, 64, (3, 3), (16, 64), 2, True, False, 2),
+    (64, 128, (5, 3), (12, 33), 0, False, True, 2),
+    (64, 64, (3, 7), (8, 32), 1, True, False, 2),
 ]
 
 
-@pytest.mark.parametrize("cin,cout,kernel,hw,act,with_res,with_sums", _ROWS_CASES)
-def test_conv_rows_cl_equals_conv_cl(cin, cout, kernel, hw, act, with_res, with_sums):
+@pytest.mark.parametrize("cin,cout,kernel,hw,act,with_res,with_sums,mt", _ROWS_CASES)
+def test_conv_rows_cl_equals_conv_cl(cin, cout, kernel, hw, act, with_res, with_sums, mt):
     """csrc/conv_rows.hip (input rows staged through LDS once per kernel row) against float64 and against conv_cl: the
     same fmaf chains in a different stage order (ky, chunk, kx) -- <= 2e-5 of the output range vs float64; channel slices,
     residual, channel sums as for conv_cl."""
@@ -736,7 +740,7 @@ def test_conv_rows_cl_equals_conv_cl(cin, cout, kernel, hw, act, with_res, with_
     out_wide = torch.full((b, h, w, cout + 8), 7.0, device=DEV)
     out = out_wide[..., 4:4 + cout].permute(0, 3, 1, 2)
     sums = torch.full((b, ops.conv_sum_chunks(h, w), cout), 3.0, device=DEV) if with_sums else None
-    got = ops.conv_rows_cl(x, ops.conv_prepare(wt, 1, order="rows"), bias, act, cout, kernel, residual=res, out=out, chan_sums=sums)
+    got = ops.conv_rows_cl(x, ops.conv_prepare(wt, mt, order="rows"), bias, act, cout, kernel, mt=mt, residual=res, out=out, chan_sums=sums)
     want = F.conv2d(x.double(), wt.double(), bias.double(), 1, (kh // 2, kw // 2))
     if with_res:
         want = want + res.double()
@@ -746,11 +750,11 @@ def test_conv_rows_cl_equals_conv_cl(cin, cout, kernel, hw, act, with_res, with_
     assert err <= 2e-5
     assert (out_wide[..., :4] == 7.0).all() and (out_wide[..., 4 + cout:] == 7.0).all()
     sums2 = torch.empty_like(sums) if with_sums else None
-    ref = ops.conv_cl(x, ops.conv_prepare(wt, 1), bias, act, cout, kernel, mt=1, residual=res, chan_sums=sums2)
+    ref = ops.conv_cl(x, ops.conv_prepare(wt, mt), bias, act, cout, kernel, mt=mt, residual=res, chan_sums=sums2)
     assert (got - ref).abs().max().item() <= 1e-5 * want.abs().max().item()
     if with_sums:
         assert (sums - sums2).abs().max().item() <= 1e-5 * sums2.abs().max().item()
-    again = ops.conv_rows_cl(x, ops.conv_prepare(wt, 1, order="rows"), bias, act, cout, kernel, residual=res)
+    again = ops.conv_rows_cl(x, ops.conv_prepare(wt, mt, order="rows"), bias, act, cout, kernel, mt=mt, residual=res)
     assert torch.equal(again, got.contiguous(memory_format=torch.channels_last)) or torch.equal(again, got)
 
 

@@ -54,9 +54,12 @@ for name, cin, cout, (kh, kw), stride, (h, w) in LAYERS:
         t = timeit(lambda: ops.conv_cl(x, wp, bias, 1, cout, (kh, kw), stride=stride, mt=mt))
         res.append((t, mt))
     if ops.conv_rows_ok((kh, kw), stride, cin, cout):
-        wr = ops.conv_prepare(wt, 1, order="rows")
-        t = timeit(lambda: ops.conv_rows_cl(x, wr, bias, 1, cout, (kh, kw)))
-        res.append((t, 0))                       # printed as "mt0" = the row-staging kernel (32 outputs per block)
+        for rmt in (1, 2):
+            if cout % (32 * rmt):
+                continue
+            wr = ops.conv_prepare(wt, rmt, order="rows")
+            t = timeit(lambda: ops.conv_rows_cl(x, wr, bias, 1, cout, (kh, kw), mt=rmt))
+            res.append((t, -rmt))                # printed as "mt-1" / "mt-2" = the row-staging kernel at 32 / 64 outputs per block
     best = min(res)
     tot_lib += t_lib; tot_own += best[0]
     print("%-18s %6.2f GF  MIOpen %.3f (+epi %.3f) ms %5.1f TF | own " % (name, gf, t_conv, t_lib, gf / t_conv) +
