@@ -20,12 +20,8 @@
 
 namespace smos {
 
-// DA ("direct A", KW = 3 and MT = 1 only): the weight fragments are requested by every wave for itself straight from
-// global memory, two stages ahead, instead of travelling through the block's LDS ring -- no ring, no barrier in the loop,
-// the four waves of a block run independently (an experiment on how much of the remaining stall is the lockstep).
-template <int KW, int MT, bool RES, bool SUMS, bool DA = false>
+template <int KW, int MT, bool RES, bool SUMS>
 __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
-  static_assert(!DA || (KW == 3 && MT == 1), "direct-A variant: KW = 3, MT = 1");
   extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 * MT float4 | bias | 4 waves x 2 row buffers
   constexpr int kSlot = 256 * MT;
   constexpr int kWt = 32 + KW - 1;                  // pixels of a staged row
@@ -211,94 +207,6 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
     }
   };
 
-  if constexpr (DA) {
-    // ---- direct-A variant ----
-    float4 bA[4], bB[4];
-    float4 a0[4], a1[4], a2[4];          // fragment sets of stages kx = 0, 1, 2 of a group (KW = 3: the set index is kx)
-    auto load_af = [&](float4 (&set)[4]) {
-      const float4* wsrc = a.w + (int64_t)(pa_g < total ? pa_slice : 0) * kSlot + lane;
-#pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) set[i4] = wsrc[i4 * 64];
-      ++pa_g;
-      pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;
-    };
-    auto mfma_da = [&](const float4 (&af)[4], const float4& bv, int i4, bool lo) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4].x : af[i4].z, lo ? bv.x : bv.z, acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? af[i4].y : af[i4].w, lo ? bv.y : bv.w, acc[0], 0, 0, 0);
-    };
-    load_af(a0);
-    fill_request();                       // group 0
-    fill_advance();
-    load_af(a1);
-    fill_write(0);
-    if (RES && c_left == 1) request_residual();
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (256 * k < a.cout) bias_lds[tid + 256 * k] = bias_r[k];
-    ring_barrier();                       // the only block-wide barrier: publishes the bias
-    read_b(bA, 0, 0);
-    // stage kx of a group: acur = this stage's fragments, apre = the set stage + 2 is requested into
-#define SMOS_DSTAGE(KX, acur, apre, bc, bn, buf)                                \
-  do {                                                                          \
-    mfma_da(acur, bc[0], 0, true);                                              \
-    SMOS_FENCE();                                                               \
-    load_af(apre);                                                              \
-    SMOS_FENCE();                                                               \
-    mfma_da(acur, bc[0], 0, false);                                             \
-    SMOS_FENCE();                                                               \
-    mfma_da(acur, bc[1], 1, true);                                              \
-    SMOS_FENCE();                                                               \
-    if constexpr ((KX) == 0) {                                                  \
-      fill_request();                                                           \
-      fill_advance();                                                           \
-    }                                                                           \
-    SMOS_FENCE();                                                               \
-    mfma_da(acur, bc[1], 1, false);                                             \
-    SMOS_FENCE();                                                               \
-    if constexpr ((KX) == KW - 1) fill_write((buf) ^ 1);                        \
-    SMOS_FENCE();                                                               \
-    mfma_da(acur, bc[2], 2, true);                                              \
-    SMOS_FENCE();                                                               \
-    if constexpr ((KX) == KW - 1) read_b(bn, (buf) ^ 1, 0);                     \
-    else read_b(bn, (buf), (KX) + 1);                                           \
-    SMOS_FENCE();                                                               \
-    mfma_da(acur, bc[2], 2, false);                                             \
-    mfma_da(acur, bc[3], 3, true);                                              \
-    mfma_da(acur, bc[3], 3, false);                                             \
-    SMOS_FENCE();                                                               \
-    if (--c_left == 0) {                                                        \
-      epilogue();                                                               \
-      c_left = a.nstage;                                                        \
-      ++c_it;                                                                   \
-    }                                                                           \
-    if (RES && c_left == 1) request_residual();                                 \
-  } while (0)
-    // set rotation: stage kx uses set kx and requests stage + 2 into set (kx + 2) % 3; B sets alternate with the stage parity
-#define SMOS_DGROUP_E(buf)                       \
-  do {                                           \
-    SMOS_DSTAGE(0, a0, a2, bA, bB, buf);         \
-    SMOS_DSTAGE(1, a1, a0, bB, bA, buf);         \
-    SMOS_DSTAGE(2, a2, a1, bA, bB, buf);         \
-  } while (0)
-#define SMOS_DGROUP_O(buf)                       \
-  do {                                           \
-    SMOS_DSTAGE(0, a0, a2, bB, bA, buf);         \
-    SMOS_DSTAGE(1, a1, a0, bA, bB, buf);         \
-    SMOS_DSTAGE(2, a2, a1, bB, bA, buf);         \
-  } while (0)
-    int G = 0;
-#pragma unroll 1
-    for (; G + 2 <= total_groups; G += 2) {
-      SMOS_DGROUP_E(0);
-      SMOS_DGROUP_O(1);
-    }
-    if (G < total_groups) SMOS_DGROUP_E(0);
-#undef SMOS_DSTAGE
-#undef SMOS_DGROUP_E
-#undef SMOS_DGROUP_O
-    return;
-  }
-
   float4 bA[4], bB[4], af[4][MT];
   float4 ae0, ae1, ao0, ao1;      // weight slices of odd / even stages on their way to the ring (stage g parks slice g + 1)
   // ---- prologue: row of group 0 staged, weight slice 0 in the ring, slices 1 and 2 in registers ----
@@ -421,18 +329,17 @@ __global__ __launch_bounds__(256, 2) void conv_rows(ConvArgs a) {
 
 using namespace smos;
 
-template <int KW, int MT, bool RES, bool SUMS, bool DA = false>
+template <int KW, int MT, bool RES, bool SUMS>
 static int launch_rows(const ConvArgs& a, hipStream_t s) {
   const size_t rows = (size_t)4 * 2 * (32 + KW - 1) * 36 * sizeof(float);
-  // (the direct-A variant leaves the ring unused; the layout is kept)
   const size_t lds = (size_t)4 * 256 * MT * sizeof(float4) + (size_t)((a.cout + 255) / 256 * 256) * sizeof(float) + rows;
   KernelSetup ks;
-  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_rows<KW, MT, RES, SUMS, DA>), 4 * 256 * MT * sizeof(float4) + 8192 + rows, 256, &ks, "conv_rows_cl"))
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_rows<KW, MT, RES, SUMS>), 4 * 256 * MT * sizeof(float4) + 8192 + rows, 256, &ks, "conv_rows_cl"))
     return rc;
   const int per_cu = ks.per_cu < 2 ? ks.per_cu : 2;
   const int64_t cap = (int64_t)ks.cus * per_cu;
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
-  hipLaunchKernelGGL((conv_rows<KW, MT, RES, SUMS, DA>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_rows<KW, MT, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_rows_cl");
 }
 
@@ -471,12 +378,6 @@ extern "C" int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* w
   a.o_bytes = (int)(B * H * W * out_pitch * 4);
   a.cout = (int)Cout;
   hipStream_t s = (hipStream_t)stream;
-  static const bool direct_a = [] { const char* e = getenv("SMOS_CONV_ROWS_DA"); return e && atoi(e) != 0; }();   // experiment
-  if (direct_a && KW == 3 && mt == 1) {
-    if (chan_sums) return launch_rows<3, 1, false, true, true>(a, s);
-    if (res) return launch_rows<3, 1, true, false, true>(a, s);
-    return launch_rows<3, 1, false, false, true>(a, s);
-  }
 #define SMOS_ROWS_DISPATCH(KW_)                                                                  \
   if (KW == KW_) {                                                                               \
     if (mt == 1) {                                                                               \
