@@ -125,6 +125,35 @@ def test_fused_engine_equals_module_graph(model):
                 assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
 
 
+def test_engine_variants_agree(model):
+    """The engine's A/B switches select other kernels for the same function: row-staging convolution on / off / also at 64
+    outputs per block, ChannelAtt pool sums from the conv epilogue or from their own pass.  Same fp32 products, other
+    summation orders: 1e-5 of the range; every variant leaves the default flags behind."""
+    frames = list(cases.e2e_frames(2))
+    model.fast_inference, model.engine_layout = True, "cl"
+    with torch.no_grad():
+        eng = model._engine_for(torch.zeros(1, device=DEV))
+    assert eng is not None and eng.layout == "cl"
+    default = (eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums)
+    outs = []
+    try:
+        for rows, rows_mt, sums in (default, (0, 1, True), (3, 2, True), (3, 1, False)):
+            eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums = rows, rows_mt, sums
+            memory, res = None, []
+            with torch.no_grad():
+                for i, batch in enumerate(frames):
+                    tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+                    pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+                    res.append((pred.clone(), memory.clone()))
+            outs.append(res)
+    finally:
+        eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums = default
+    for other in outs[1:]:
+        for (p0, m0), (p1, m1) in zip(outs[0], other):
+            assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
+            assert (m0 - m1).abs().max().item() <= 5e-5 * m0.abs().max().item()      # observed 1.5e-5 (behind two LayerNorms)
+
+
 @pytest.mark.parametrize("fill", ["lidar", "empty_sample", "dense_corner"])
 def test_sparse_stem_equals_dense_downsample(model, fill):
     """header_bev[0] computed on the occupied cells only (stem_mark + per-parity-class GEMMs + stem_epilogue) against
