@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="with --graph: TTA groups replayed concurrently on HIP streams")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the encoder of frame t+1 with the decoder of frame t")
+    ap.add_argument("--no-raw", action="store_true", help="skip the PCIe-inclusive raw-scan leg (profiling runs: keeps the trace to "
+                                                         "the headline step)")
     ap.add_argument("--cpu-scans", type=int, default=4, help="timed scans of the CPU baseline (0 = skip); 4 scans = about 15 s")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
@@ -461,7 +463,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
-        if world == 1:
+        if world == 1 and not args.no_raw:
             # PCIe-inclusive variant (never `value`): raw scans uploaded every step, preprocessing on the device
             raw_runner = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=not args.no_pipeline)
             from streammos_amd import synth as _synth

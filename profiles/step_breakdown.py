@@ -7,7 +7,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "tta_argmax" in r["Kernel_Name"]]
-a, b = idx[-3], idx[-2]
+# the interval of median duration among the steps of the timed region (the first ones are warm-up, the last ones border on
+# what the bench runs after its timed region)
+spans = sorted(((int(rows[idx[k + 1]]["End_Timestamp"]) - int(rows[idx[k]]["End_Timestamp"]), k) for k in range(len(idx) // 3, len(idx) - 2)))
+k = spans[len(spans) // 2][1]
+a, b = idx[k], idx[k + 1]
 step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 if len(sys.argv) > 2:
