@@ -160,3 +160,53 @@ def test_stage2_training_step_matches_reference_golden(golden):
     torch.optim.SGD(trainable, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-3).step()
     moved = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
     assert moved and all(k.startswith("refine.") for k in moved)
+
+
+def test_stage2_step_under_ddp_with_the_rccl_backend():
+    """The reference's stage-2 wrapping on the device -- SyncBatchNorm conversion, everything but `refine.*` frozen,
+    DistributedDataParallel(find_unused_parameters=True) on the 'nccl' (= RCCL) backend (train_StreamMOS_seg.py:165-190) -- with
+    a process group of one rank (a one-GPU box cannot host two RCCL ranks).  The DDP-wrapped step must give the loss and
+    the gradients of the bare module: the reducer's hooks and the custom autograd functions (VoxelMaxPool, MSDeformAttn on
+    the HIP kernels) work together."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from streammos_amd.refapi.config import StreamMOS_seg as cfg
+    from streammos_amd.refapi.models import StreamMOS_seg
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        base = StreamMOS_seg.AttNet(cfg.get_config()[2])
+        base.load_state_dict(synth.seeded_state_dict(base.state_dict()), strict=True)
+        StreamMOS_seg.freeze_for_stage2(base)
+        base = base.to(DEV).train()
+        frames = list(cases.e2e_frames(3))
+        gen = torch.Generator(device="cpu").manual_seed(9)
+        batch = {}
+        for i, f in enumerate(frames):
+            for k, v in f.items():
+                batch["%s_%d" % (k, i)] = torch.from_numpy(v).to(DEV)
+            batch["pcds_target_%d" % i] = torch.randint(0, 3, (2, cases.E2E_POINTS, 1), generator=gen).to(DEV)
+            batch["pcds_bev_target_%d" % i] = torch.randint(0, 3, (2, 256, 256, 1), generator=gen).to(DEV)
+            batch["pcds_bf_target_%d" % i] = torch.randint(0, 3, (2, cases.E2E_POINTS, 1), generator=gen).to(DEV)
+        plain = copy.deepcopy(base)
+        torch.manual_seed(123)                       # train mode: the dropout masks of the two runs must be the same
+        loss_plain = plain(batch)
+        loss_plain.backward()
+        wrapped = DistributedDataParallel(torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(base)), device_ids=[0],
+                                          find_unused_parameters=True)
+        torch.manual_seed(123)
+        loss_ddp = wrapped(batch)
+        loss_ddp.backward()
+        assert torch.isfinite(loss_ddp) and abs(loss_ddp.item() - loss_plain.item()) <= 1e-5 * abs(loss_plain.item())
+        got = {k: p.grad for k, p in wrapped.module.named_parameters() if p.grad is not None}
+        want = {k: p.grad for k, p in plain.named_parameters() if p.grad is not None}
+        assert set(got) == set(want) and len(got) > 0 and all(k.startswith("refine.") for k in got)
+        for k in got:
+            assert (got[k] - want[k]).abs().max().item() <= 1e-5 * max(want[k].abs().max().item(), 1e-12), k
+    finally:
+        dist.destroy_process_group()
