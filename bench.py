@@ -7,9 +7,12 @@ Workload = BASELINE.json configs[1] on synthetic 120k-point scans (no SemanticKI
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched under torch.distributed.run, one rank per GPU, each rank streams its OWN sequence
-(sequence sharding, no collective on the data path) -> "scaling": "weak".
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU, each rank streams its OWN sequence (sequence sharding, no collective on the data path) ->
+"scaling": "weak".  Under torch.distributed.run (WORLD_SIZE / RANK in the environment) the ranks are the launcher's; a
+plain ``python bench.py --gpus N`` starts the N ranks ITSELF (streammos_amd.launch.self_launch: the parent never touches
+the GPU, the ranks are children of a torch.distributed.run child) -- the reference's README.md:97 launch line folded into
+the program.  ``--dry-launch`` walks the same spawn path with gloo ranks that only join the group and time a barrier
+(no GPU needed: the CPU test of the launch path).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -232,6 +235,30 @@ def cpu_baseline(frames, state_dict, n_timed):
                       "(forward + TTA argmax, voting excluded)" % (1, n_timed, FRAME_POINT_NUM)}
 
 
+def dry_launch(args):
+    """The launch path without the GPU: every rank joins a gloo group, the barrier-bracketed "timed region" is K
+    barriers, the MAX over ranks is taken as in the real run and rank 0 prints the line with the group's real size."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    elapsed = 0.0
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, world = float(t.item()), dist.get_world_size()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (no GPU work)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_launch": True, "barrier_ms": round(1e3 * elapsed / max(args.steps, 1), 4),
+                          "config": {"parallelism": "sequence-shard x%d" % world}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,10 +278,19 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=4, help="timed scans of the CPU baseline (0 = skip); 4 scans = about 15 s")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only rehearse the rank launch: gloo ranks join the group, time a barrier, rank 0 prints n_gpus")
     ap.add_argument("--label-log", default=None,
                     help="write the launch-ordered list of kernel labels of one step to this JSON file (used by "
                          "profiles/pmc_summary.py to tell the conv launches of a rocprofv3 --pmc pass apart; needs --no-pipeline)")
     args = ap.parse_args()
+
+    from streammos_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # no launcher around us: become the launcher.  Nothing above this line touches the GPU (importing torch does not).
+        sys.exit(launch.self_launch(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+    if args.dry_launch:
+        return dry_launch(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -271,6 +307,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()            # the ranks that really joined the group
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -6,7 +6,9 @@
 Writes ``<out>/predictions/NNNNNN.label`` (network output, the files val_StreamMOS.py:121-126 writes) and, with
 voting, ``<out>/refined/NNNNNN.label`` (the files voxel_voting.py:244-249 writes).  If the sequence has
 ``labels/``, the static / moving IoU of both is printed (utils/metric.py formula).  Several sequences are
-sharded over ranks with ``streaming.shard_sequences`` when launched under ``torch.distributed.run``.
+sharded over ranks with ``streaming.shard_sequences``: under ``torch.distributed.run`` the ranks are the launcher's;
+with ``--gpus N`` and no launcher around it the program starts its N ranks itself (``launch.self_launch``, the
+reference's README.md:97 launch line folded in; the parent never touches the GPU).
 """
 import argparse
 import json
@@ -15,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import kitti, preprocess, streaming, synth
+from . import kitti, launch, preprocess, streaming, synth
 
 
 def load_model(checkpoint=None, device="cuda:0", seg=False):
@@ -121,11 +123,19 @@ def main():
                     help="voxel_instance_voting.py instead of voxel_voting.py for the refined labels (needs --seg: the "
                          "clusters come from the `_bf` prediction)")
     ap.add_argument("--limit", type=int, default=None)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks (one per GPU) the sequences are sharded over; > 1 without a launcher: started by this program")
+    ap.add_argument("--frame-point-num", type=int, default=160000, help="Val.frame_point_num of config/StreamMOS.py:44")
     ap.add_argument("--device-preprocess", action="store_true",
                     help="range filter / pose alignment / TTA / quantisation on the GPU: only raw scans cross PCIe")
     args = ap.parse_args()
+    if args.gpus > 1 and not launch.under_launcher():
+        import sys
+        sys.exit(launch.self_launch(args.gpus, sys.argv[1:], module="streammos_amd.run_sequence"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    device = args.device or "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    # SMOS_BENCH_ONE_DEVICE=1 (rehearsal on a one-GPU box, as in bench.py): every rank uses cuda:0
+    local = 0 if os.environ.get("SMOS_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    device = args.device or "cuda:%d" % local
     lengths = {d: len(os.listdir(os.path.join(d, "velodyne"))) for d in args.seq_dir}
     mine = streaming.shard_sequences(lengths, world)[rank]
     if args.instance_vote and not args.seg:
@@ -134,7 +144,9 @@ def main():
     vote = False if args.no_vote else ("instance" if args.instance_vote else True)
     for d in mine:
         out = os.path.join(args.out_dir, os.path.basename(os.path.normpath(d))) if len(args.seq_dir) > 1 else args.out_dir
-        print(json.dumps(run_sequence(model, d, out, device, vote=vote, limit=args.limit, device_preprocess=args.device_preprocess)), flush=True)
+        res = run_sequence(model, d, out, device, vote=vote, limit=args.limit, frame_point_num=args.frame_point_num,
+                           device_preprocess=args.device_preprocess)
+        print(json.dumps(dict(res, rank=rank, world=world)), flush=True)
 
 
 if __name__ == "__main__":

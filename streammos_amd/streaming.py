@@ -348,9 +348,17 @@ class StreamRunner:
         ring of pinned staging buffers: a copy from pageable memory would hold the host until the stream has drained, and
         pinning per call costs milliseconds."""
         cache = self.__dict__.setdefault("_raw_cache", collections.OrderedDict())
+        cur = torch.cuda.current_stream(self.device)
         hit = cache.get(id(scan))
         if hit is not None and hit[0] is scan:
-            return hit[1]
+            # the copy may still be in flight on ANOTHER stream (the window of frame t is uploaded on main, the look-ahead
+            # window of frame t+1 re-uses two of its scans on the side stream, and the other way round when the look-ahead
+            # misses): order this stream behind the copy and tell the allocator about the second user
+            _, dev, done, owner = hit
+            if owner != cur.cuda_stream:
+                cur.wait_event(done)
+                dev.record_stream(cur)
+            return dev
         host = scan if torch.is_tensor(scan) else torch.from_numpy(np.ascontiguousarray(scan, dtype=np.float32))
         if host.is_cuda:
             return host
@@ -370,10 +378,13 @@ class StreamRunner:
             staged.copy_(host)
             dev = staged.to(self.device, non_blocking=True)
             slot[1] = torch.cuda.Event()
-            slot[1].record(torch.cuda.current_stream(self.device))
+            slot[1].record(cur)
+            done = slot[1]
         else:
             dev = host.to(self.device, non_blocking=True)
-        cache[id(scan)] = (scan, dev)
+            done = torch.cuda.Event()
+            done.record(cur)
+        cache[id(scan)] = (scan, dev, done, cur.cuda_stream)
         while len(cache) > 16:
             cache.popitem(last=False)
         return dev

@@ -1,0 +1,71 @@
+"""The multi-rank entry points as a user (or the driver) starts them: `python bench.py --gpus N` and
+`python -m streammos_amd.run_sequence --gpus N` with no launcher around them create their ranks themselves
+(streammos_amd/launch.py; the reference's launch line is README.md:97 / val_StreamMOS.py:205-218).
+
+A one-GPU box cannot host two RCCL ranks, so the rehearsal knobs put both ranks on cuda:0 with a gloo group
+(SMOS_BENCH_BACKEND=gloo, SMOS_BENCH_ONE_DEVICE=1): the spawn path, the barrier-bracketed timing, the MAX over ranks and
+the per-rank sequence shard are the ones an 8-GPU run uses; only the backend name differs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from streammos_amd import kitti, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SMOS_BENCH_BACKEND="gloo", SMOS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_bench_gpus_2_spawns_two_ranks_on_the_device():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--frames", "3", "--cpu-scans", "0", "--no-raw"], capture_output=True, text=True, timeout=900, env=_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = lines[0]
+    print("2 ranks on one device: %.1f scans/s aggregate, %.2f ms/step" % (line["value"], line["ms_per_step"]))
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "sequence-shard x2"
+    assert line["steps"] == 3 and line["value"] > 0 and abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 0.01 * line["value"]
+
+
+def _write_sequence(seq, n, first):
+    (seq / "velodyne").mkdir(parents=True)
+    for k in range(n):
+        synth.synthetic_scan(first + k, 16, 120).tofile(seq / "velodyne" / ("%06d.bin" % k))
+    kitti.write_poses(seq / "poses.txt", [synth.synthetic_pose(k) for k in range(n)])
+    kitti.write_calibration(seq / "calib.txt")
+
+
+def test_run_sequence_gpus_2_shards_whole_sequences(tmp_path):
+    """Three sequences over two self-started ranks: longest-first assignment (streaming.shard_sequences), every scan of
+    every sequence gets its prediction and refined file, and the sharded files equal those of a one-rank run."""
+    lens = {"11": 9, "12": 5, "13": 4}
+    for name, n in lens.items():
+        _write_sequence(tmp_path / "sequences" / name, n, first=10 * int(name))
+    dirs = [str(tmp_path / "sequences" / name) for name in lens]
+    base = [sys.executable, "-m", "streammos_amd.run_sequence", "--frame-point-num", "2048", "--seq-dir"] + dirs
+    two = subprocess.run(base + ["--out-dir", str(tmp_path / "two"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=900, env=_env(), cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    res = {r["sequence"]: r for r in (json.loads(l) for l in two.stdout.splitlines() if l.startswith("{"))}
+    assert {k: v["scans"] for k, v in res.items()} == lens
+    assert all(r["world"] == 2 for r in res.values())
+    assert res["11"]["rank"] != res["12"]["rank"] and res["12"]["rank"] == res["13"]["rank"]     # 9 | 5 + 4
+    one = subprocess.run(base + ["--out-dir", str(tmp_path / "one")], capture_output=True, text=True, timeout=900,
+                         env=_env(), cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    for name, n in lens.items():
+        for k in range(n):
+            for sub in ("predictions", "refined"):
+                a = np.fromfile(tmp_path / "two" / name / sub / ("%06d.label" % k), dtype=np.uint32)
+                b = np.fromfile(tmp_path / "one" / name / sub / ("%06d.label" % k), dtype=np.uint32)
+                assert a.shape == b.shape and np.array_equal(a, b), (name, k, sub)

@@ -99,3 +99,34 @@ def test_step_raw_with_look_ahead_equals_plain_step_raw():
             assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
             for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
                 assert torch.equal(la, lb)
+
+
+def test_look_ahead_orders_the_side_stream_behind_uploads_pending_on_main():
+    """The window of frame 0 is uploaded on the main stream; the look-ahead window of frame 1 re-uses two of those scans
+    on the side stream through the upload cache.  With main's copies held back by a long spin kernel queued in front of
+    them, the side stream reads stale memory unless the cache hit waits for the copy's event (the cache
+    kept no record of the uploading stream).  Results must equal the serial raw path bit for bit."""
+    from streammos_amd import streaming
+    from streammos_amd.refapi.config import StreamMOS as cfg
+    from streammos_amd.refapi.models import StreamMOS
+    model = StreamMOS.AttNet(cfg.get_config()[2])
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict()), strict=True)
+    scans = [synth.synthetic_scan(k, 16, 120) for k in range(5)]
+    poses = [synth.synthetic_pose(k) for k in range(5)]
+    plain = streaming.StreamRunner(model, DEV, vote=False)
+    ahead = streaming.StreamRunner(model, DEV, vote=False, pipeline=True)
+    want = []
+    for i in range(3):
+        idx = preprocess.window_indices(i, 5, 3)
+        want.append(plain.step_raw([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048)["pred_cls"].clone())
+    torch.cuda.synchronize()
+    # poison the allocator's free blocks so that a read before the copy lands sees garbage, not an old copy of the scan
+    junk = [torch.full((s.size,), float("nan"), device=DEV) for s in scans for _ in range(2)]
+    del junk
+    for i in range(3):
+        idx = preprocess.window_indices(i, 5, 3)
+        nxt = preprocess.window_indices(i + 1, 5, 3)
+        torch.cuda._sleep(200_000_000)          # ~0.1 s in front of this step's H2D copies on the main stream
+        got = ahead.step_raw([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048,
+                             next_scans=[scans[j] for j in nxt], next_poses=[poses[j] for j in nxt])["pred_cls"]
+        assert torch.equal(got, want[i]), i

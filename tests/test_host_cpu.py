@@ -226,6 +226,33 @@ def test_sequence_sharding_world_size_2_gloo(tmp_path):
     assert line == {"total": 921 + 1061 + 3281 + 631 + 1901, "max_elapsed": 2.0, "world": 2}
 
 
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must create the two ranks itself (the flag was
+    parsed and ignored).  --dry-launch walks the same spawn path with gloo ranks that only join the group and time a
+    barrier, so it runs without a GPU; the JSON line's n_gpus is the size of the group that really formed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "3"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # ONE line, from rank 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["dry_launch"] and lines[0]["config"]["parallelism"] == "sequence-shard x2"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-launch"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_self_launch_reports_a_failing_rank(tmp_path):
+    """A rank that dies must fail the whole launch (non-zero exit of the parent)."""
+    from streammos_amd import launch
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    assert launch.self_launch(2, [], script=str(bad), timeout=120) != 0
+    good = tmp_path / "good.py"
+    good.write_text("import os\nassert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n")
+    assert launch.self_launch(2, [], script=str(good), timeout=120) == 0
+
+
 def test_kitti_formats_round_trip(tmp_path):
     from streammos_amd import kitti
     poses = [synth.synthetic_pose(k) for k in range(4)]
