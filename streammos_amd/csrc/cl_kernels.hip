@@ -424,7 +424,7 @@ extern "C" int smos_downsample_epilogue_cl(const float* a, int64_t a_pitch, cons
   SMOS_REQUIRE(a && p && bias && out && al16(a) && al16(p) && al16(bias) && al16(out) && a_pitch % 4 == 0 && p_pitch % 4 == 0 &&
                    out_pitch % 4 == 0, "downsample_epilogue_cl: pointers / pitches must be 16-byte aligned");
   const int Ho = (int)((H + 2 - 3) / stride + 1), Wo = (int)((W + 2 - 3) / stride + 1);
-  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < (1LL << 31) && B * H < (1LL << 31), "downsample_epilogue_cl: too many elements for 32-bit indices");
+  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < kMaxTotal32 && B * H < (1LL << 31), "downsample_epilogue_cl: too many elements for 32-bit indices");
   hipLaunchKernelGGL(downsample_epilogue_cl2, dim3(grid_for(B * Ho * Wo * (C / 4), kBlock, 256 * 16)), dim3(kBlock), 0,
                      (hipStream_t)stream, a, a_pitch, p, p_pitch, bias, out, out_pitch, (int)B, (int)(C / 4), (int)H, (int)W, Ho, Wo,
                      (int)stride);

@@ -66,8 +66,11 @@ Geometry geometry(const at::Tensor& pcds_feat, const at::Tensor& pcds_ind, const
   g.feat_stride = {pcds_feat.stride(0), pcds_feat.stride(1), pcds_feat.stride(2)};
   g.out_stride = voxel_out.strides().vec();
   g.out_size = voxel_out.sizes().slice(2).vec();
+  TORCH_CHECK(scale_rate.numel() == g.d, "scale_rate must hold one factor per grid dimension");
+  // The D scale factors have to come back to the host: one small synchronising copy per call.  It cannot be cached by
+  // tensor identity -- the reference builds a FRESH device tensor per call (deep_point/__init__.py:32), so an address is
+  // reused with other values; a CPU scale_rate tensor (what a maintainer would pass) costs no sync.
   at::Tensor sc = scale_rate.to(at::kCPU, at::kFloat).contiguous();
-  TORCH_CHECK(sc.numel() == g.d, "scale_rate must hold one factor per grid dimension");
   g.scale.assign(sc.data_ptr<float>(), sc.data_ptr<float>() + g.d);
   return g;
 }
@@ -82,10 +85,13 @@ void voxel_maxpooling_forward(at::Tensor pcds_feat, at::Tensor pcds_ind, at::Ten
   check_input(voxel_out_size, "voxel_out_size");
   check_input(voxel_out_stride, "voxel_out_stride");
   check_input(output_size, "output_size");
-  check_input(scale_rate, "scale_rate");
+  TORCH_CHECK(scale_rate.is_contiguous(), "scale_rate must be contiguous");     // may live on the host: no sync then
   TORCH_CHECK(voxel_max_idx.scalar_type() == at::kLong, "voxel_max_idx must be int64");
   TORCH_CHECK(pcds_ind.scalar_type() == pcds_feat.scalar_type() && voxel_out.scalar_type() == pcds_feat.scalar_type(),
               "pcds_feat / pcds_ind / voxel_out dtypes differ");
+  TORCH_CHECK(voxel_max_idx.sizes() == voxel_out.sizes(), "voxel_max_idx must have voxel_out's shape");
+  TORCH_CHECK(pcds_ind.device() == pcds_feat.device() && voxel_out.device() == pcds_feat.device() &&
+              voxel_max_idx.device() == pcds_feat.device(), "all tensors must live on pcds_feat's device");
   Geometry g = geometry(pcds_feat, pcds_ind, voxel_out, scale_rate);
   c10::DeviceGuard guard(pcds_feat.device());
   at::Tensor flag = at::zeros({4}, pcds_feat.options().dtype(at::kInt));   // "saw a negative feature" scratch
@@ -108,9 +114,15 @@ void voxel_maxpooling_backward(at::Tensor pcds_feat, at::Tensor pcds_ind, at::Te
   check_input(voxel_out_size, "voxel_out_size");
   check_input(voxel_out_stride, "voxel_out_stride");
   check_input(output_size, "output_size");
-  check_input(scale_rate, "scale_rate");
+  TORCH_CHECK(scale_rate.is_contiguous(), "scale_rate must be contiguous");
   TORCH_CHECK(grad_voxel_out.sizes() == voxel_out.sizes() && grad_pcds_feat.sizes() == pcds_feat.sizes(),
               "gradient shapes must match their tensors");
+  TORCH_CHECK(pcds_ind.scalar_type() == pcds_feat.scalar_type() && voxel_out.scalar_type() == pcds_feat.scalar_type() &&
+              grad_voxel_out.scalar_type() == pcds_feat.scalar_type() && grad_pcds_feat.scalar_type() == pcds_feat.scalar_type(),
+              "pcds_feat / pcds_ind / voxel_out / gradient dtypes differ");
+  TORCH_CHECK(pcds_ind.device() == pcds_feat.device() && voxel_out.device() == pcds_feat.device() &&
+              grad_voxel_out.device() == pcds_feat.device() && grad_pcds_feat.device() == pcds_feat.device(),
+              "all tensors must live on pcds_feat's device");
   Geometry g = geometry(pcds_feat, pcds_ind, voxel_out, scale_rate);
   c10::DeviceGuard guard(pcds_feat.device());
   int rc = smos_voxel_maxpool_bwd(pcds_feat.data_ptr(), g.feat_stride.data(), pcds_ind.data_ptr(), voxel_out.data_ptr(),
@@ -151,6 +163,16 @@ Dims msda_dims(const at::Tensor& value, const at::Tensor& spatial_shapes, const 
   TORCH_CHECK(value.dim() == 4 && sampling_loc.dim() == 6 && attn_weight.dim() == 5, "unexpected tensor ranks");
   Dims q{value.size(0), value.size(1), value.size(2), value.size(3), spatial_shapes.size(0), sampling_loc.size(1),
          sampling_loc.size(4)};
+  // what the raw pointers handed to the C ABI are assumed to be: one dtype, one device, the exact shapes
+  TORCH_CHECK(sampling_loc.scalar_type() == value.scalar_type() && attn_weight.scalar_type() == value.scalar_type(),
+              "value / sampling_loc / attn_weight dtypes differ");
+  TORCH_CHECK(sampling_loc.device() == value.device() && attn_weight.device() == value.device() &&
+              spatial_shapes.device() == value.device() && level_start_index.device() == value.device(),
+              "all tensors must live on value's device");
+  TORCH_CHECK(spatial_shapes.dim() == 2 && spatial_shapes.size(1) == 2 && level_start_index.numel() == q.l,
+              "spatial_shapes must be [L,2] and level_start_index [L]");
+  TORCH_CHECK(sampling_loc.sizes() == at::IntArrayRef({q.n, q.lq, q.m, q.l, q.p, 2}), "sampling_loc must be [N,Lq,M,L,P,2]");
+  TORCH_CHECK(attn_weight.sizes() == at::IntArrayRef({q.n, q.lq, q.m, q.l, q.p}), "attn_weight must be [N,Lq,M,L,P]");
   const int64_t step = std::min<int64_t>(q.n, im2col_step);
   TORCH_CHECK(step > 0 && q.n % step == 0, "batch(", q.n, ") must divide im2col_step(", step, ")");
   return q;
@@ -174,7 +196,9 @@ std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor& value, const a
                                                 const at::Tensor& attn_weight, const at::Tensor& grad_output,
                                                 const int im2col_step) {
   Dims q = msda_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step);
-  TORCH_CHECK(grad_output.is_cuda(), "grad_output must be a CUDA tensor");
+  TORCH_CHECK(grad_output.is_cuda() && grad_output.device() == value.device() && grad_output.scalar_type() == value.scalar_type(),
+              "grad_output must be a CUDA tensor of value's dtype on value's device");
+  TORCH_CHECK(grad_output.sizes() == at::IntArrayRef({q.n, q.lq, q.m * q.d}), "grad_output must be [N,Lq,M*D]");
   c10::DeviceGuard guard(value.device());
   at::Tensor go = grad_output.contiguous();
   at::Tensor grad_value = at::zeros_like(value);

@@ -12,6 +12,11 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kBlock = 256;        // 4 waves, one per SIMD
 constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 resident blocks: grid-stride beyond that
 
+// Largest element count a 32-bit grid-stride loop (`for (int i = ...; i < total; i += gridDim.x * blockDim.x)`) may be
+// given: the counter of the last iteration is up to one grid stride past `total` and must still be a positive int
+// (grids are capped at 256 * 32 blocks of kBlock threads = 2^21 elements per stride).
+constexpr int64_t kMaxTotal32 = (1LL << 31) - (1LL << 22);
+
 void set_error(const char* fmt, ...);
 
 inline int grid_for(int64_t work_items, int block = kBlock, int64_t cap = kMaxGrid) {

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void upconv_xpass(const float* __restrict__
     const float* zrow = z + ((int64_t)(b * Hs + ys) * Ws) * (9 * C) + (3 * ky) * C + q;
     float4 v0[3], v1[3];
     float w0[3], w1[3];
+    bool inb[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xs = X + kx - 1;
@@ -63,14 +64,19 @@ __global__ __launch_bounds__(kBlock) void upconv_xpass(const float* __restrict__
       const float* p = zrow + (int64_t)l.i0 * (9 * C) + kx * C;
       v0[kx] = *reinterpret_cast<const float4*>(p);
       v1[kx] = *reinterpret_cast<const float4*>(p + (int64_t)l.step * (9 * C));
-      w0[kx] = in ? l.w0 : 0.0f;
-      w1[kx] = in ? l.w1 : 0.0f;
+      w0[kx] = l.w0;
+      w1[kx] = l.w1;
+      inb[kx] = in;
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      acc.x += w0[kx] * v0[kx].x + w1[kx] * v1[kx].x; acc.y += w0[kx] * v0[kx].y + w1[kx] * v1[kx].y;
-      acc.z += w0[kx] * v0[kx].z + w1[kx] * v1[kx].z; acc.w += w0[kx] * v0[kx].w + w1[kx] * v1[kx].w;
+      // the loads are unconditional (clamped address); a padded tap is dropped by a select on the VALUE at its consumer,
+      // not by a zero weight: 0 * Inf / NaN of a border element must not leak into the output
+      const float4 a0 = inb[kx] ? v0[kx] : zero4, a1 = inb[kx] ? v1[kx] : zero4;
+      acc.x += w0[kx] * a0.x + w1[kx] * a1.x; acc.y += w0[kx] * a0.y + w1[kx] * a1.y;
+      acc.z += w0[kx] * a0.z + w1[kx] * a1.z; acc.w += w0[kx] * a0.w + w1[kx] * a1.w;
     }
     *reinterpret_cast<float4*>(t + (int64_t)i * 4) = acc;
   }
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void upconv_ypass(const float* __restrict__
     const float4 bv = *reinterpret_cast<const float4*>(bias + q);
     float4 v0[2][3], v1[2][3];
     float w0[2][3], w1[2][3];
+    bool inb[2][3];
 #pragma unroll
     for (int si = 0; si < 2; ++si) {
       const YSrc s = si == 0 ? s1 : s2;
@@ -110,16 +117,19 @@ __global__ __launch_bounds__(kBlock) void upconv_ypass(const float* __restrict__
         const float* p = s.t + ((int64_t)((b * 3 + ky) * s.Hs + l.i0) * Wo + X) * C + q;
         v0[si][ky] = *reinterpret_cast<const float4*>(p);
         v1[si][ky] = *reinterpret_cast<const float4*>(p + (int64_t)l.step * Wo * C);
-        w0[si][ky] = in ? l.w0 * s.on : 0.0f;
-        w1[si][ky] = in ? l.w1 * s.on : 0.0f;
+        w0[si][ky] = l.w0;
+        w1[si][ky] = l.w1;
+        inb[si][ky] = in & (s.on != 0.0f);
       }
     }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int si = 0; si < 2; ++si)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        acc.x += w0[si][ky] * v0[si][ky].x + w1[si][ky] * v1[si][ky].x; acc.y += w0[si][ky] * v0[si][ky].y + w1[si][ky] * v1[si][ky].y;
-        acc.z += w0[si][ky] * v0[si][ky].z + w1[si][ky] * v1[si][ky].z; acc.w += w0[si][ky] * v0[si][ky].w + w1[si][ky] * v1[si][ky].w;
+        const float4 a0 = inb[si][ky] ? v0[si][ky] : zero4, a1 = inb[si][ky] ? v1[si][ky] : zero4;   // select on the value (NaN-safe)
+        acc.x += w0[si][ky] * a0.x + w1[si][ky] * a1.x; acc.y += w0[si][ky] * a0.y + w1[si][ky] * a1.y;
+        acc.z += w0[si][ky] * a0.z + w1[si][ky] * a1.z; acc.w += w0[si][ky] * a0.w + w1[si][ky] * a1.w;
       }
     float4 o = make_float4(acc.x + bv.x, acc.y + bv.y, acc.z + bv.z, acc.w + bv.w);
     if (act == 1) {
@@ -142,7 +152,7 @@ extern "C" int smos_upconv_xpass(const float* z, float* t, int64_t B, int64_t Hs
                                  smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 4 == 0 && Wo > 0, "upconv_xpass: bad sizes (C %% 4 must be 0)");
   SMOS_REQUIRE(z && t && aligned16(z) && aligned16(t), "upconv_xpass: null / unaligned pointer");
-  SMOS_REQUIRE(B * 3 * Hs * Wo * (C / 4) < (1LL << 31) && B * Hs < (1LL << 31), "upconv_xpass: too many elements for 32-bit indices");
+  SMOS_REQUIRE(B * 3 * Hs * Wo * (C / 4) < kMaxTotal32 && B * Hs < (1LL << 31), "upconv_xpass: too many elements for 32-bit indices");
   hipLaunchKernelGGL(upconv_xpass, dim3(grid_for(B * 3 * Hs * Wo * (C / 4), kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, z, t,
                      (int)B, (int)Hs, (int)Ws, (int)(C / 4), (int)Wo);
   return check_launch("upconv_xpass");
@@ -155,7 +165,7 @@ extern "C" int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const flo
                "upconv_ypass: bad arguments");
   SMOS_REQUIRE(conv_a && bias && out && aligned16(conv_a) && aligned16(out) && aligned16(bias) && (!t1 || (aligned16(t1) && H1 > 0)) &&
                    (!t2 || (aligned16(t2) && H2 > 0)), "upconv_ypass: null / unaligned pointer");
-  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < (1LL << 31) && (t1 || t2) && B * 3 * (H1 > H2 ? H1 : H2) < (1LL << 31),
+  SMOS_REQUIRE(B * Ho * Wo * (C / 4) < kMaxTotal32 && (t1 || t2) && B * 3 * (H1 > H2 ? H1 : H2) < (1LL << 31),
                "upconv_ypass: too many elements for 32-bit indices / no source");
   // an absent source: the other one again, switched off -- every load of the kernel stays unconditional
   YSrc s1{t1 ? t1 : t2, (int)(t1 ? H1 : H2), t1 ? 1.0f : 0.0f}, s2{t2 ? t2 : t1, (int)(t2 ? H2 : H1), t2 ? 1.0f : 0.0f};

@@ -250,7 +250,9 @@ class InferenceEngine:
         hipGraphs captured from one engine for several TTA groups replay concurrently with the addresses baked in
         (namespace = group index, ops.set_workspace_namespace in StreamRunner._capture) -- a shared scratch would be a data
         race in each case."""
-        table = p.__dict__.setdefault("ws", {})
+        table = p.__dict__.get("ws")
+        if table is None:
+            table = p.__dict__["ws"] = ops.new_block_scratch()     # registered: release_stream_workspaces purges it
         key = (torch.cuda.current_stream(self.device).cuda_stream, ops._ws_namespace)
         ws = table.get(key)
         if ws is None or ws.numel() < n_floats:
@@ -366,7 +368,10 @@ class InferenceEngine:
         on channels-last maps: one launch of csrc/conv_igemm.hip; the operand-ordered copy of w is made once per (weight,
         mt).  With SMOS_OWN_CONV=0: MIOpen conv + the separate bias / activation / residual pass."""
         cout, cin, kh, kw = w.shape
-        if not self.own_conv or cin % 32 or cout % 32:
+        if not self.own_conv or not ops.conv_cl_supported(x, cout, (kh, kw), stride, residual, out):
+            # MIOpen + the separate epilogue pass: channel counts the MFMA tiling does not cover, operands of 2 GiB and more
+            if chan_sums is not None:
+                raise RuntimeError("InferenceEngine._conv: channel sums need the own conv kernel")
             y = F.conv2d(x, w, None, stride, (kh // 2, kw // 2))
             if bias is None and act == NONE and residual is None and out is None:
                 return y
@@ -403,7 +408,8 @@ class InferenceEngine:
         if not p.att:
             return self._conv(y, p.w2, p.b2, RELU, residual=x, out=out)
         bsz, c, h, w = y.shape
-        if self.own_conv and self.fused_gate_sums and c % 32 == 0 and 1024 % c == 0:
+        if (self.own_conv and self.fused_gate_sums and c % 32 == 0 and c <= 256 and 1024 % c == 0 and
+                ops.conv_cl_supported(y, c, tuple(p.w2.shape[2:]))):
             # the conv's epilogue leaves the per-row-segment channel sums behind: no pass over y2 for the average pool
             chunks = ops.conv_sum_chunks(h, w)
             ws = self._block_ws(p, bsz * c * (chunks + 1))

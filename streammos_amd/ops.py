@@ -477,6 +477,29 @@ def conv_prepare(w, mt, order="taps"):
     return v.reshape(-1).contiguous()
 
 
+def conv_cl_supported(x, cout, kernel, stride=1, residual=None, out=None):
+    """The hard limits of smos_conv_cl / smos_conv_rows_cl (the SMOS_REQUIREs of csrc/conv_igemm.hip:486-500), as a
+    predicate the engine asks BEFORE it routes a layer to the own kernels: Cin / Cout multiples of 32, Cout <= 2048,
+    kernel <= 7x7, stride 1 or 2, and every operand below 2 GiB (the kernels address through 32-bit buffer offsets; a
+    16-stream batch of 128-channel 256x256 maps is 2.1 GB).  Shapes only: works on meta tensors."""
+    kh, kw = kernel
+    b, cin, h, w = x.shape
+    if cin % 32 or cout % 32 or cout > 2048 or not (1 <= kh <= 7 and 1 <= kw <= 7) or stride not in (1, 2):
+        return False
+    ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (w + 2 * (kw // 2) - kw) // stride + 1
+    if ho <= 0 or wo <= 0:
+        return False
+
+    def pitch(t, c):
+        return t.stride(3) if t is not None and t.dim() == 4 and t.stride(1) == 1 else c
+    limit = 1 << 31
+    if b * h * w * pitch(x, cin) * 4 >= limit or b * ho * wo * pitch(out, cout) * 4 >= limit:
+        return False
+    if residual is not None and b * ho * wo * pitch(residual, cout) * 4 >= limit:
+        return False
+    return True
+
+
 def conv_rows_ok(kernel, stride, cin, cout):
     """Shapes smos_conv_rows_cl covers (stride 1, "same" padding, KW in {3, 5, 7})."""
     kh, kw = kernel
@@ -710,17 +733,57 @@ def _stream_workspace(tag, shape, dtype, device, zero=False):
     return buf[:need].view(shape)
 
 
+class BlockScratch(dict):
+    """{(HIP stream, namespace): buffer} of one ChannelAtt block (engine._block_ws); a dict that can be weakly referenced,
+    so the registry below does not keep a dead engine's scratch alive."""
+    __slots__ = ("__weakref__",)
+    __hash__ = object.__hash__            # identity: the registry is a WeakSet
+    __eq__ = object.__eq__
+
+
+import weakref as _weakref
+
+_block_ws_tables = _weakref.WeakSet()
+_owner_tokens = iter(range(1, 1 << 62))
+
+
+def new_workspace_owner():
+    """A token for scratch namespaces that is never handed out twice (id(obj) can be: a later runner allocated at a freed
+    runner's address would alias its namespaces)."""
+    return next(_owner_tokens)
+
+
+def new_block_scratch():
+    table = BlockScratch()
+    _block_ws_tables.add(table)
+    return table
+
+
 def release_stream_workspaces(device=None, stream=None, owner=None):
-    """Drops the per-stream scratch: all of it, one device's, one HIP stream's, or (owner = the id a graph runner put into
-    its namespace) what that runner's captured graphs use.  StreamRunner.close() calls this."""
+    """Drops the per-stream scratch: all of it, one device's, one HIP stream's, or (owner = the token a graph runner put
+    into its namespace, ``new_workspace_owner``) what that runner's captured graphs use -- the sparse-stage buffers, the
+    scatter's flag words and the channel-attention blocks' plane sums alike.  StreamRunner.close() calls this."""
+    def owned(ns):
+        return isinstance(ns, tuple) and len(ns) > 1 and ns[1] == owner
     for key in list(_stem_ws):
-        ns = key[4]
-        owned = isinstance(ns, tuple) and len(ns) > 1 and ns[1] == owner
         if owner is not None:
-            if owned:
+            if owned(key[4]):
                 del _stem_ws[key]
         elif (device is None or key[0] == str(device)) and (stream is None or key[1] == stream):
             del _stem_ws[key]
+    for key in list(_flag_ws):                       # (device, stream, namespace)
+        if owner is not None:
+            if owned(key[2]):
+                del _flag_ws[key]
+        elif (device is None or str(key[0]) == str(device)) and (stream is None or key[1] == stream):
+            del _flag_ws[key]
+    for table in list(_block_ws_tables):             # engine._block_ws: {(stream, namespace): buffer} per ChannelAtt block
+        for key in list(table):
+            if owner is not None:
+                if owned(key[1]):
+                    del table[key]
+            elif stream is None or key[0] == stream:
+                del table[key]
 
 
 class StemPlan:

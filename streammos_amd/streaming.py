@@ -230,6 +230,7 @@ class StreamRunner:
         self.use_graph = graph
         self.split = max(1, int(split))
         self._graphs = None
+        self._ws_owner = ops.new_workspace_owner()      # names this runner's scratch namespaces (never reused, unlike id())
         # pipeline=True: only the temporal fusion needs the previous frame, so the encoder of frame t+1 (point MLP,
         # scatters, the BEV / range-view stages: ~60 % of the work) is issued on a second HIP stream while frame t
         # is decoded on the main one.  step() must then be given the next frame's inputs (one frame of look-ahead).
@@ -268,7 +269,7 @@ class StreamRunner:
     def _capture_groups(self, dev, eng, k, per, side):
         for gi in range(k):
             sl = slice(gi * per, (gi + 1) * per)
-            ops.set_workspace_namespace(("graph", id(self), gi))    # per-group scratch: the groups' graphs replay concurrently
+            ops.set_workspace_namespace(("graph", self._ws_owner, gi))    # per-group scratch: the groups' graphs replay concurrently
             g_in = {key: dev[key][sl].clone() for key in self._KEYS}
             batch = {key: g_in[key].unsqueeze(0) for key in self._KEYS}
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -327,7 +328,7 @@ class StreamRunner:
             ops.release_stream_workspaces(self.device, self._side.cuda_stream)
         if self._graphs is not None:                 # the captured graphs go first: their kernels use that scratch
             self._graphs = self._groups = None
-            ops.release_stream_workspaces(owner=id(self))
+            ops.release_stream_workspaces(owner=self._ws_owner)
 
     def upload(self, sample, raw_scan=None):
         """Host sample (streammos_amd.preprocess.build_sample) -> device-resident inputs."""

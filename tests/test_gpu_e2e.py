@@ -69,7 +69,10 @@ def test_stream_runner_with_voting_matches_oracle(model):
                                                        ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), memory)
         want_lab, _ = net_torch.tta_labels(want)
         agree = (out["labels"].cpu().long() == want_lab).float().mean().item()
-        assert agree >= 0.995, (i, agree)
+        err = (out["pred_cls"].cpu() - want).abs().max().item() / want.abs().max().item()
+        print("runner frame %d vs oracle: logits %.2e of range, TTA labels %.6f" % (i, err, agree))
+        # ~10x the observed error (fp32 on both sides, summation order only); 2048 points: one flipped label = 4.9e-4
+        assert err <= 2e-5 and agree >= 0.9995, (i, err, agree)
         raw_preds.append(out["raw_labels"].cpu().numpy())
         for fid, lab in out["voted"]:
             voted[fid] = lab.cpu().numpy()
@@ -353,8 +356,9 @@ def test_graph_replay_equals_eager(model):
 
 def test_concurrent_streams_equal_separate_streams(model):
     """configs[2] in small: two sequences batched through MultiStreamRunner give each stream the labels it gets
-    when streamed alone (the network is batch-independent; MIOpen may pick another algorithm per batch size, hence a
-    tolerance on the logits instead of equality)."""
+    when streamed alone.  The network is batch-independent and the own kernels are deterministic; only the library GEMMs
+    of the attention block (hipBLASLt) may pick another kernel for the doubled token count, hence a (tight) tolerance on the
+    logits; the labels must be identical."""
     spec = preprocess.VoxelSpec()
     seqs = []
     for q in range(2):
@@ -382,8 +386,10 @@ def test_concurrent_streams_equal_separate_streams(model):
         pred, outs = ms.step(ms.batch_inputs(devs), [seqs[q][1][i] for q in range(2)])
         for q in range(2):
             want_pred, want_raw = solo[q][i]
-            assert (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() <= 1e-4 * want_pred.abs().max().item()
-            assert (outs[q]["raw_labels"] == want_raw).float().mean().item() >= 0.9995
+            err = (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() / want_pred.abs().max().item()
+            flips = int((outs[q]["raw_labels"] != want_raw).sum().item())
+            print("2 streams, frame %d, stream %d: batched vs solo %.2e of range, %d labels differ" % (i, q, err, flips))
+            assert err <= 1e-5 and flips == 0, (i, q, err, flips)
 
 
 def test_pipelined_runner_equals_plain_runner(model):
@@ -431,8 +437,11 @@ def test_seg_variant_engine_matches_reference_golden(golden):
             pred, bf, a0, a1, a2, memory = m.infer(tb, i, memory)
             for got, key in ((pred, "seg_f%d_pred" % i), (bf, "seg_f%d_bf_pred" % i)):
                 ref = g[key]
-                assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
-                assert (got.cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.995
+                err = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
+                agree = (got.cpu().numpy().argmax(1) == ref.argmax(1)).mean()
+                print("seg golden frame %d %s: %.2e of range, labels %.6f" % (i, key, err, agree))
+                # the stage-1 bar (test_infer_matches_reference_golden): ~10x the error observed on MI355X
+                assert err <= 2e-5 and agree >= 0.9999, (i, key, err, agree)
     spec = preprocess.VoxelSpec()
     scans = [synth.synthetic_scan(k, 16, 120) for k in range(4)]
     poses = [synth.synthetic_pose(k) for k in range(4)]
@@ -469,6 +478,7 @@ def test_eight_concurrent_streams_full_size(model):
     torch.set_num_threads(bench.host_cores())
     mem_cpu = None
     worst = [0.0, 1.0]
+    total_raw_flips = [0] * S
     for f in range(n_frames):
         devs = [up.upload(per_stream[q][f][0], per_stream[q][f][1]) for q in range(S)]
         pred, outs = ms.step(ms.batch_inputs(devs), [per_stream[q][f][2] for q in range(S)])
@@ -480,8 +490,15 @@ def test_eight_concurrent_streams_full_size(model):
             worst = [max(worst[0], err), min(worst[1], same)]
             assert err <= 1e-5 and same >= 0.9999, (f, q, err, same)
             assert [k for k, _ in outs[q]["voted"]] == [k for k, _ in want_voted]
-            for (_, a), (_, b) in zip(outs[q]["voted"], want_voted):
-                assert (a == b).float().mean().item() >= 0.9999
+            for (k, a), (_, b) in zip(outs[q]["voted"], want_voted):
+                # voting is integer work on the raw labels: identical raw labels -> identical voted labels; count, do not tolerate
+                vote_flips = int((a != b).sum().item())
+                raw_flips = int((outs[q]["raw_labels"] != want_raw).sum().item())
+                if vote_flips or raw_flips:
+                    print("8 streams, frame %d stream %d voted frame %d: %d voted / %d raw labels differ from the solo run"
+                          % (f, q, k, vote_flips, raw_flips))
+                assert vote_flips <= 2 * max(raw_flips, total_raw_flips[q]), (f, q, k, vote_flips, raw_flips)
+            total_raw_flips[q] += int((outs[q]["raw_labels"] != want_raw).sum().item())
         s0 = per_stream[0][f][0]
         with torch.no_grad():
             want, _, _, _, mem_cpu = oracle.stage_forward(*(torch.from_numpy(s0[k]) for k in

@@ -65,8 +65,10 @@ def test_step_raw_equals_host_preprocessed_step():
         sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
         oa = a.step(a.upload(sample, scans[i]), poses[i])
         ob = b.step_raw([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048)
-        assert (oa["pred_cls"] - ob["pred_cls"]).abs().max().item() <= 2e-3 * oa["pred_cls"].abs().max().item()
-        assert (oa["raw_labels"] == ob["raw_labels"]).float().mean().item() >= 0.999
+        err = (oa["pred_cls"] - ob["pred_cls"]).abs().max().item() / oa["pred_cls"].abs().max().item()
+        same = (oa["raw_labels"] == ob["raw_labels"]).float().mean().item()
+        print("step_raw vs host-preprocessed step, frame %d: logits %.2e of range, raw labels %.6f" % (i, err, same))
+        assert err <= 2e-3 and same >= 0.999, (i, err, same)
         assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
         for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
             assert (la == lb).float().mean().item() >= 0.999

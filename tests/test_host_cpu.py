@@ -377,3 +377,22 @@ def test_seg_variant_layout_and_cpu_graph_match_reference(golden, monkeypatch):
     assert len(out) == 6
     for got, key in ((out[0], "seg_f0_pred"), (out[1], "seg_f0_bf_pred")):
         assert np.abs(got.numpy() - g[key]).max() <= 1e-4 * np.abs(g[key]).max()
+
+
+def test_conv_cl_supported_mirrors_the_kernel_limits():
+    """The engine asks ops.conv_cl_supported before it routes a layer to the own conv kernels: channel
+    multiples, Cout <= 2048, kernel <= 7, and the 2 GiB operand limit of the 32-bit buffer offsets.  Shapes only."""
+    from streammos_amd import ops
+
+    def cl(b, c, h, w):
+        return torch.empty((b, h, w, c), device="meta").permute(0, 3, 1, 2)
+    assert ops.conv_cl_supported(cl(4, 128, 256, 256), 64, (3, 3))
+    assert ops.conv_cl_supported(cl(32, 128, 256, 256), 64, (3, 3))                 # 8 streams: 1.07 GB
+    assert not ops.conv_cl_supported(cl(64, 128, 256, 256), 64, (3, 3))             # 16 streams: 2.1 GB input
+    assert not ops.conv_cl_supported(cl(64, 64, 256, 256), 128, (3, 3))             # 2.1 GB output
+    assert not ops.conv_cl_supported(cl(4, 48, 64, 64), 64, (3, 3))                 # Cin % 32
+    assert not ops.conv_cl_supported(cl(4, 64, 64, 64), 4096, (1, 1))               # Cout > 2048
+    assert not ops.conv_cl_supported(cl(4, 64, 64, 64), 64, (9, 9))
+    assert not ops.conv_cl_supported(cl(4, 64, 64, 64), 64, (3, 3), stride=3)
+    wide = torch.empty((44, 256, 256, 192), device="meta").permute(0, 3, 1, 2)[:, :64]   # a channel slice: the PITCH counts
+    assert not ops.conv_cl_supported(wide, 64, (3, 3))
