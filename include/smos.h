@@ -274,6 +274,21 @@ int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep, const floa
                  float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t KH,
                  int32_t KW, int32_t stride, int32_t pad_h, int32_t pad_w, int32_t mt, int32_t act, float* chan_sums,
                  smos_stream_t stream);
+/* smos_conv_cl for the stride-1 3x3 "same" layers in the Winograd F(2x2, 3x3) form (csrc/conv_wino.hip): 4 instead of 9
+ * multiply-adds per output and channel pair, arithmetic still plain fp32 -- the weights are transformed on the host in
+ * float64 (U = G g G^T, rounded once), the input and output transforms are additions.  Replaces the same reference layers as
+ * smos_conv_cl (networks/backbone.py:136-159, networks/multi_view_encoder.py:446-447,478-497) where the kernel is 3x3 and
+ * the stride 1.  Cin % 16 == 0, mb in {1, 2}: 16 * mb output channels per block, Cout % (16 * mb) == 0.  Operand order:
+ *   wprep[((((ct * (Cin / 16) + cc) * 4 + i) * mb + m) * 4 + xi) * 64 + lane][nu]
+ *       = U[xi][nu] of w[ct * 16 * mb + m * 16 + (lane & 15)][cc * 16 + 4 * (lane >> 4) + i],  U = G w G^T (4 x 4),
+ *   G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]].
+ * chan_sums (may be NULL; needs res == NULL): [B][chunks][Cout], chunks = smos_conv_wino_sum_chunks(H, W); entry
+ *   (b, chunk, c) = sum of out[b, y, x, c] over two output rows x 32 columns (chunk = ((y / 8) * ceil(W / 32) + x / 32) * 4
+ *   + (y % 8) / 2; parts outside the image contribute 0).  Summation order is fixed (run-to-run identical). */
+int64_t smos_conv_wino_sum_chunks(int64_t H, int64_t W);
+int smos_conv_wino_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res, int64_t res_pitch,
+                      float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t mb,
+                      int32_t act, float* chan_sums, smos_stream_t stream);
 
 /* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
  * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels

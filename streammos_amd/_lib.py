@@ -47,6 +47,8 @@ SIGNATURES = {
     "smos_conv_cl_sum_chunks": [i64, i64],
     "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "smos_conv_rows_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp],
+    "smos_conv_wino_sum_chunks": [i64, i64],
+    "smos_conv_wino_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],

@@ -1,0 +1,382 @@
+// Stride-1 3x3 convolution (channels-last fp32, "same" padding) in the Winograd F(2x2, 3x3) form on the matrix cores of
+// gfx950, with the bias + activation (+ residual, + channel sums) epilogue fused -- the 36 stride-1 3x3 layers of the
+// network (networks/backbone.py:136-159 BasicBlock, multi_view_encoder.py:478-497 the 3x3 of an Unbalance block, :446-447
+// conv_1 / conv_2) do 4 multiply-adds per output and channel pair instead of 9:
+//
+//     Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A        d: 4x4 input patch, Y: 2x2 outputs, "." elementwise
+//
+// The weights U = G g G^T are transformed in float64 on the host and rounded once (ops.conv_wino_prepare); B^T d B and
+// A^T M A consist of additions only (the +-1 / 0 matrices of F(2,3)), so the arithmetic stays plain fp32:
+// tools/winograd_numerics.py measures 2.2e-7 .. 5.4e-7 per layer against float64 (direct fp32: 3.1e-7 .. 3.8e-7) and
+// 1.2e-6 of the logit range end to end against the reference's golden outputs (bar 2e-5).
+//
+// Mapping.  The 16 transform positions (xi, nu) are 16 independent GEMMs  M[xi nu][cout][tile] = U[xi nu][cout][cin] *
+// V[xi nu][cin][tile]  with K = Cin, run on v_mfma_f32_16x16x4_f32 (exact f32; 16 couts x 16 tiles x 4 cins per
+// instruction, 4 accumulator registers): all 16 accumulators of a (16-cout, 16-tile) pair stay in registers for the
+// whole K loop -- 64 * MB registers for the 16 * MB couts a wave computes -- and the output transform happens in the
+// lane (a lane holds 4 consecutive couts of ONE tile for every (xi, nu)), followed by the epilogue and 16-byte stores.
+//
+//   work item  = 8 output rows x 32 columns (4 x 16 tiles) x 16 * MB output channels; one block (4 waves) per item, wave w
+//                = tile row w (16 tiles side by side: the MFMA column), blocks persistent over a contiguous item range
+//                (cout tile fastest, XCD-aware order as in conv_igemm).
+//   chunk      = 16 input channels = 4 k-steps; lane (q = lane >> 4, tx = lane & 15) supplies cin 4 q + i of the chunk at
+//                k-step i (the weights are packed to match), so its four k-steps read the four channels of ONE float4.
+//   B operand  = transformed activations.  The block stages the chunk's (8 + 2) x (32 + 2) input region ONCE from global
+//                memory (fully coalesced 16-byte buffer loads, zero padding = out-of-range offsets), transposed on the way
+//                into LDS: pixel pitch 17 words, channel 4 q + i at word 4 i + q -- a k-step's 16 patch reads (ds_read_b32,
+//                immediate offsets) are then bank-conflict free (bank = 2 tx + q + const).  Per k-step a lane reads its 4x4
+//                patch, runs the 32 additions of B^T d B and owns the 16 B operands.  Two region buffers: chunk g + 1 is
+//                requested at the start of chunk g and written during its last k-step.
+//   A operand  = U, streamed through a two-slot LDS ring, one k-step (16 x 16 MB x 4 floats) per slot, requested a k-step
+//                ahead; a lane reads 4 consecutive (nu) operands per ds_read_b128.  One barrier per k-step.
+//   bytes      = per cin: 64 B x 16 MB of weights + ~85 B x 16 of activations for 16 x 16 MB x 64 MACs: 13 B/clk/CU at
+//                MB = 2 with the matrix pipe saturated -- inside what an XCD's L2 serves a CU (~29 B/clk).
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace smos {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoArgs {
+  const float* x;      // [B, H, W, *] row pitch xp (floats)
+  const float4* w;     // [cout tile][chunk][k-step][mb][xi][lane = q * 16 + m][nu]  (ops.conv_wino_prepare)
+  const float* bias;   // [Cout] or null
+  const float* res;    // [B, H, W, *] row pitch rp, or null
+  float* out;          // [B, H, W, *] row pitch op
+  float* sums;         // SUMS: [B][yb * xb * 4][Cout] per-(item, wave) channel sums of the output
+  int64_t xp, rp, op;
+  int B, H, W;
+  int nchunk;          // Cin / 16
+  int nct;             // Cout / (16 * MB)
+  int yb, xb;          // ceil(H / 8), ceil(W / 32)
+  int n_items;         // B * yb * xb * nct
+  float slope;         // activation: max(v, 0) + slope * min(v, 0)
+  int x_bytes, r_bytes, o_bytes, cout;
+};
+
+constexpr int kWPP = 17;                          // words per staged pixel: 16 channels + 1 (odd pitch)
+constexpr int kWRegW = 34, kWRegH = 10;           // staged region: (8 + 2) rows x (32 + 2) columns
+constexpr int kWRegPix = kWRegW * kWRegH;         // 340 pixels = 1360 float4 = 5.3 per thread
+constexpr int kWInWords = kWRegPix * kWPP;        // 5780 words (23 120 B) per buffer
+
+// sum over the 16 lanes of a DPP row, delivered in its last lane (tx = 15); fixed order -> run-to-run identical
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+  return v;
+}
+
+struct WinoItem {
+  int b, y0, x0, ct;
+};
+
+template <int MB, bool RES, bool SUMS>
+__global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4* w_lds = reinterpret_cast<float4*>(lds + 2 * kWInWords);       // two slots of 256 * MB float4
+  constexpr int kSlot = 256 * MB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, tx = lane & 15;
+
+  const int per_block = (a.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nb = (int)gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = (int)blockIdx.x & 7;
+  const int lblock = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+  const int first = lblock * per_block;
+  const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
+  if (iters <= 0) return;
+  const int total = iters * a.nchunk;
+
+  auto item_of = [&](int it) {
+    WinoItem t;
+    int u = first + (it < iters ? it : iters - 1);
+    t.ct = u % a.nct;
+    u /= a.nct;
+    t.x0 = (u % a.xb) * 32;
+    u /= a.xb;
+    t.y0 = (u % a.yb) * 8;
+    t.b = u / a.yb;
+    return t;
+  };
+
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout * 4 : 0, 0x00020000);
+
+  // ---- staging of a chunk's input region: thread = (pixel tid / 4 + 64 k, channel group tid % 4), k = 0..5 ----
+  const int xp = (int)a.xp;
+  const int sp0 = tid >> 2, sc4 = tid & 3;
+  u32x4 st0, st1, st2, st3, st4, st5;
+#define WINO_STAGE_ONE(dst, k, t, c, valid)                                                                        \
+  do {                                                                                                             \
+    const int p_ = sp0 + 64 * (k);                                                                                 \
+    const int py_ = (p_ * 241) >> 13, px_ = p_ - 34 * py_;          /* p / 34 for p < 384 */                       \
+    const int gy_ = (t).y0 - 1 + py_, gx_ = (t).x0 - 1 + px_;                                                      \
+    const bool ok_ = (valid) & (p_ < kWRegPix) & ((unsigned)gy_ < (unsigned)a.H) & ((unsigned)gx_ < (unsigned)a.W); \
+    const unsigned off_ = ok_ ? (unsigned)((((t).b * a.H + gy_) * a.W + gx_) * xp + 16 * (c) + 4 * sc4) * 4u : 0x80000000u; \
+    dst = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off_, 0, 0);                                                 \
+  } while (0)
+#define WINO_STAGE_LOAD(t, c, valid)      \
+  do {                                    \
+    WINO_STAGE_ONE(st0, 0, t, c, valid);  \
+    WINO_STAGE_ONE(st1, 1, t, c, valid);  \
+    WINO_STAGE_ONE(st2, 2, t, c, valid);  \
+    WINO_STAGE_ONE(st3, 3, t, c, valid);  \
+    WINO_STAGE_ONE(st4, 4, t, c, valid);  \
+    WINO_STAGE_ONE(st5, 5, t, c, valid);  \
+  } while (0)
+  // channel 4 c4 + i of pixel p goes to word p * 17 + 4 i + c4 (k-step i reads word 4 i + q)
+#define WINO_PARK_ONE(buf, src, k)                            \
+  do {                                                        \
+    float* d_ = (buf) + (sp0 + 64 * (k)) * kWPP + sc4;        \
+    d_[0] = __uint_as_float(src.x);                           \
+    d_[4] = __uint_as_float(src.y);                           \
+    d_[8] = __uint_as_float(src.z);                           \
+    d_[12] = __uint_as_float(src.w);                          \
+  } while (0)
+#define WINO_STAGE_WRITE(buf)                                 \
+  do {                                                        \
+    WINO_PARK_ONE(buf, st0, 0);                               \
+    WINO_PARK_ONE(buf, st1, 1);                               \
+    WINO_PARK_ONE(buf, st2, 2);                               \
+    WINO_PARK_ONE(buf, st3, 3);                               \
+    WINO_PARK_ONE(buf, st4, 4);                               \
+    if (sp0 + 320 < kWRegPix) WINO_PARK_ONE(buf, st5, 5);     \
+  } while (0)
+
+  // ---- weights: the slice of k-step (ct, c, i) is 256 * MB consecutive float4 ----
+  float4 wr0, wr1;
+#define WINO_W_LOAD(ct, c, i)                                                                            \
+  do {                                                                                                   \
+    const float4* s_ = a.w + (int64_t)((((ct) * a.nchunk + (c)) << 2) + (i)) * kSlot + tid;               \
+    wr0 = s_[0];                                                                                         \
+    if constexpr (MB > 1) wr1 = s_[256];                                                                 \
+  } while (0)
+#define WINO_W_WRITE(slot)                                        \
+  do {                                                            \
+    w_lds[(slot) * kSlot + tid] = wr0;                            \
+    if constexpr (MB > 1) w_lds[(slot) * kSlot + 256 + tid] = wr1; \
+  } while (0)
+
+  f32x4 acc[MB][16];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[mb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane's patch origin inside a region buffer: tile (row = wave, column = tx) -> region pixel (2 wave, 2 tx), word q
+  const int in_base = ((2 * wave) * kWRegW + 2 * tx) * kWPP + q;
+
+  // ---- one k-step: patch -> B^T d B -> 16 x MB x ... MFMAs ----
+#define WINO_KSTEP(buf, i, slot)                                                                                   \
+  do {                                                                                                             \
+    const float* pin_ = (buf) + in_base + 4 * (i);                                                                 \
+    float d_[16];                                                                                                  \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                               \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) d_[4 * r_ + c_] = pin_[(r_ * kWRegW + c_) * kWPP];         \
+    float t_[16], v_[16];                                                                                          \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                             \
+      t_[c_] = d_[c_] - d_[8 + c_];                                                                                \
+      t_[4 + c_] = d_[4 + c_] + d_[8 + c_];                                                                        \
+      t_[8 + c_] = d_[8 + c_] - d_[4 + c_];                                                                        \
+      t_[12 + c_] = d_[4 + c_] - d_[12 + c_];                                                                      \
+    }                                                                                                              \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                             \
+      v_[4 * r_] = t_[4 * r_] - t_[4 * r_ + 2];                                                                    \
+      v_[4 * r_ + 1] = t_[4 * r_ + 1] + t_[4 * r_ + 2];                                                            \
+      v_[4 * r_ + 2] = t_[4 * r_ + 2] - t_[4 * r_ + 1];                                                            \
+      v_[4 * r_ + 3] = t_[4 * r_ + 1] - t_[4 * r_ + 3];                                                            \
+    }                                                                                                              \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                             \
+      float4 af_[MB];                                                                                              \
+      _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) af_[mb_] = w_lds[(slot) * kSlot + (mb_ * 4 + g_) * 64 + lane]; \
+      _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) {                                                       \
+        acc[mb_][4 * g_ + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].x, v_[4 * g_ + 0], acc[mb_][4 * g_ + 0], 0, 0, 0); \
+        acc[mb_][4 * g_ + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].y, v_[4 * g_ + 1], acc[mb_][4 * g_ + 1], 0, 0, 0); \
+        acc[mb_][4 * g_ + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].z, v_[4 * g_ + 2], acc[mb_][4 * g_ + 2], 0, 0, 0); \
+        acc[mb_][4 * g_ + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].w, v_[4 * g_ + 3], acc[mb_][4 * g_ + 3], 0, 0, 0); \
+      }                                                                                                            \
+    }                                                                                                              \
+  } while (0)
+
+  // ---- epilogue of an item: A^T M A per (cout, tile) in the lane, bias / residual / activation, 16-byte stores ----
+  auto epilogue = [&](const WinoItem& t) {
+    const int y = t.y0 + 2 * wave, x = t.x0 + 2 * tx;
+    float* srow = nullptr;
+    if constexpr (SUMS) {
+      const int chunk = (((t.y0 >> 3) * a.xb + (t.x0 >> 5)) << 2) + wave;
+      srow = a.sums + ((int64_t)t.b * (a.yb * a.xb * 4) + chunk) * a.cout;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int c0 = (t.ct * MB + mb) * 16 + 4 * q;
+      const u32x4 braw = __builtin_amdgcn_raw_buffer_load_b128(bsrd, (unsigned)c0 * 4u, 0, 0);
+      const f32x4 bv = {__uint_as_float(braw.x), __uint_as_float(braw.y), __uint_as_float(braw.z), __uint_as_float(braw.w)};
+      unsigned ooff[4];
+      bool ok[4];
+      u32x4 rr[RES ? 4 : 1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = y + (k >> 1), xx = x + (k & 1);
+        ok[k] = (yy < a.H) & (xx < a.W);
+        const int pix = (t.b * a.H + yy) * a.W + xx;
+        ooff[k] = ok[k] ? (unsigned)(pix * (int)a.op + c0) * 4u : 0x80000000u;
+        if constexpr (RES) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrd, ok[k] ? (unsigned)(pix * (int)a.rp + c0) * 4u : 0x80000000u, 0, 0);
+      }
+      f32x4 s0[4], s1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        s0[nu] = (acc[mb][nu] + acc[mb][4 + nu]) + acc[mb][8 + nu];
+        s1[nu] = (acc[mb][4 + nu] - acc[mb][8 + nu]) - acc[mb][12 + nu];
+      }
+      f32x4 yv[4];
+      yv[0] = (s0[0] + s0[1]) + s0[2];
+      yv[1] = (s0[1] - s0[2]) - s0[3];
+      yv[2] = (s1[0] + s1[1]) + s1[2];
+      yv[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[mb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 v = yv[k] + bv;
+        if constexpr (RES) {
+          v[0] += __uint_as_float(rr[k].x); v[1] += __uint_as_float(rr[k].y);
+          v[2] += __uint_as_float(rr[k].z); v[3] += __uint_as_float(rr[k].w);
+        }
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o = __builtin_fmaf(a.slope, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+          ov[e] = __float_as_uint(o);
+          if constexpr (SUMS) ssum[e] += ok[k] ? o : 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff[k], 0, 0);
+      }
+      if constexpr (SUMS) {
+        float4 sv;
+        sv.x = row16_sum(ssum[0]);
+        sv.y = row16_sum(ssum[1]);
+        sv.z = row16_sum(ssum[2]);
+        sv.w = row16_sum(ssum[3]);
+        if (tx == 15) *reinterpret_cast<float4*>(srow + c0) = sv;
+      }
+    }
+  };
+
+  // ---- prologue: region of chunk 0 in buffer 0, weights of k-step 0 in slot 0 ----
+  WinoItem cur = item_of(0);
+  WINO_STAGE_LOAD(cur, 0, true);
+  WINO_W_LOAD(cur.ct, 0, 0);
+  WINO_STAGE_WRITE(lds);
+  WINO_W_WRITE(0);
+  ring_barrier();
+
+  int it = 0, c = 0;
+  float* buf_cur = lds;
+  float* buf_nxt = lds + kWInWords;
+#pragma unroll 1
+  for (int g = 0; g < total; ++g) {
+    int c_n = c + 1, it_n = it;
+    if (c_n == a.nchunk) {
+      c_n = 0;
+      it_n = it + 1;
+    }
+    const WinoItem nxt = c_n == 0 ? item_of(it_n) : cur;           // past the last item: clamped, loads masked off
+    WINO_STAGE_LOAD(nxt, c_n, g + 1 < total);
+    WINO_W_LOAD(cur.ct, c, 1);
+    WINO_KSTEP(buf_cur, 0, 0);
+    WINO_W_WRITE(1);
+    ring_barrier();
+    WINO_W_LOAD(cur.ct, c, 2);
+    WINO_KSTEP(buf_cur, 1, 1);
+    WINO_W_WRITE(0);
+    ring_barrier();
+    WINO_W_LOAD(cur.ct, c, 3);
+    WINO_KSTEP(buf_cur, 2, 0);
+    WINO_W_WRITE(1);
+    ring_barrier();
+    WINO_W_LOAD(nxt.ct, c_n, 0);
+    WINO_KSTEP(buf_cur, 3, 1);
+    WINO_W_WRITE(0);
+    WINO_STAGE_WRITE(buf_nxt);
+    ring_barrier();
+    if (c_n == 0) {
+      epilogue(cur);
+      cur = nxt;
+    }
+    it = it_n;
+    c = c_n;
+    float* sw = buf_cur;
+    buf_cur = buf_nxt;
+    buf_nxt = sw;
+  }
+}
+
+}  // namespace smos
+
+using namespace smos;
+
+template <int MB, bool RES, bool SUMS>
+static int launch_wino(const WinoArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * kWInWords * sizeof(float) + (size_t)2 * 256 * MB * sizeof(float4);
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_wino<MB, RES, SUMS>), lds, 256, &ks, "conv_wino_cl")) return rc;
+  static const int want_per_cu = [] {
+    int v = 2;
+    if (const char* e = getenv("SMOS_WINO_BLOCKS_PER_CU")) {
+      const int n = atoi(e);
+      if (n >= 1 && n <= 8) v = n;
+    }
+    return v;
+  }();
+  const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
+  const int64_t cap = (int64_t)ks.cus * per_cu;
+  const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
+  hipLaunchKernelGGL((conv_wino<MB, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
+  return check_launch("conv_wino_cl");
+}
+
+extern "C" int64_t smos_conv_wino_sum_chunks(int64_t H, int64_t W) { return ((H + 7) / 8) * ((W + 31) / 32) * 4; }
+
+// Stride-1 3x3 "same" convolution in the Winograd F(2x2, 3x3) form.  wprep = ops.conv_wino_prepare(w, mb) (the float64
+// G g G^T of the folded weights in operand order); everything else as smos_conv_cl.  mb in {1, 2}: 16 * mb output channels
+// per block.  Replaces the same reference layers as smos_conv_cl where the kernel is 3x3 and the stride 1.
+extern "C" int smos_conv_wino_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, const float* res,
+                                 int64_t res_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                                 int64_t Cout, int32_t mb, int32_t act, float* chan_sums, smos_stream_t stream) {
+  SMOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && (mb == 1 || mb == 2) && Cout % (16 * mb) == 0 &&
+                   act >= 0 && act <= 2, "conv_wino_cl: Cin must be a multiple of 16 and Cout of 16 * mb (mb in {1, 2})");
+  SMOS_REQUIRE(Cout <= 2048, "conv_wino_cl: more than 2048 output channels");
+  SMOS_REQUIRE(x && wprep && out && x_pitch >= Cin && out_pitch >= Cout && x_pitch % 4 == 0 && out_pitch % 4 == 0 &&
+                   (!res || (res_pitch >= Cout && res_pitch % 4 == 0)), "conv_wino_cl: null pointer / bad pitch");
+  SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
+                 reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(wprep) | reinterpret_cast<uintptr_t>(chan_sums)) & 15) == 0,
+               "conv_wino_cl: pointers must be 16-byte aligned");
+  SMOS_REQUIRE(B * H * W * x_pitch * 4 < (1LL << 31) && B * H * W * out_pitch * 4 < (1LL << 31) &&
+                   (!res || B * H * W * res_pitch * 4 < (1LL << 31)), "conv_wino_cl: a tensor larger than 2 GiB (32-bit buffer offsets)");
+  const int64_t yb = (H + 7) / 8, xb = (W + 31) / 32, nct = Cout / (16 * mb);
+  SMOS_REQUIRE(B * yb * xb * nct < (1LL << 30) && nct * (Cin / 16) < (1LL << 24), "conv_wino_cl: too many tiles");
+  SMOS_REQUIRE(!(chan_sums && res), "conv_wino_cl: channel sums need res == NULL");
+  WinoArgs a;
+  a.x = x; a.w = reinterpret_cast<const float4*>(wprep); a.bias = bias; a.res = res; a.out = out; a.sums = chan_sums;
+  a.xp = x_pitch; a.rp = res_pitch; a.op = out_pitch;
+  a.B = (int)B; a.H = (int)H; a.W = (int)W;
+  a.nchunk = (int)(Cin / 16); a.nct = (int)nct; a.yb = (int)yb; a.xb = (int)xb; a.n_items = (int)(B * yb * xb * nct);
+  a.slope = act == 0 ? 1.0f : act == 1 ? 0.0f : 0.01f;
+  a.x_bytes = (int)(B * H * W * x_pitch * 4);
+  a.r_bytes = res ? (int)(B * H * W * res_pitch * 4) : 0;
+  a.o_bytes = (int)(B * H * W * out_pitch * 4);
+  a.cout = (int)Cout;
+  hipStream_t s = (hipStream_t)stream;
+  if (chan_sums) return mb == 1 ? launch_wino<1, false, true>(a, s) : launch_wino<2, false, true>(a, s);
+  if (res) return mb == 1 ? launch_wino<1, true, false>(a, s) : launch_wino<2, true, false>(a, s);
+  return mb == 1 ? launch_wino<1, false, false>(a, s) : launch_wino<2, false, false>(a, s);
+}

@@ -89,7 +89,8 @@ void voxel_maxpooling_forward(at::Tensor pcds_feat, at::Tensor pcds_ind, at::Ten
   TORCH_CHECK(voxel_max_idx.scalar_type() == at::kLong, "voxel_max_idx must be int64");
   TORCH_CHECK(pcds_ind.scalar_type() == pcds_feat.scalar_type() && voxel_out.scalar_type() == pcds_feat.scalar_type(),
               "pcds_feat / pcds_ind / voxel_out dtypes differ");
-  TORCH_CHECK(voxel_max_idx.sizes() == voxel_out.sizes(), "voxel_max_idx must have voxel_out's shape");
+  // one slot per POINT (deep_point/__init__.py:27: torch.full([BS, N], -1)); the kernel writes BS * N int64 words
+  TORCH_CHECK(voxel_max_idx.numel() == pcds_ind.size(0) * pcds_ind.size(1), "voxel_max_idx must be [BS, N]");
   TORCH_CHECK(pcds_ind.device() == pcds_feat.device() && voxel_out.device() == pcds_feat.device() &&
               voxel_max_idx.device() == pcds_feat.device(), "all tensors must live on pcds_feat's device");
   Geometry g = geometry(pcds_feat, pcds_ind, voxel_out, scale_rate);

@@ -602,6 +602,77 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
     return out
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def conv_wino_prepare(w, mb):
+    """w [Cout, Cin, 3, 3] (BatchNorm folded) -> the weight block of smos_conv_wino_cl: U = G w G^T per (cout, cin) in
+    float64, rounded once to float32, in MFMA operand order [cout tile][cin chunk of 16][k-step i][mb][xi][lane][nu] with
+    lane = q * 16 + m holding U[xi][nu] of w[ct*16*mb + mb_i*16 + m][chunk*16 + 4*q + i] (include/smos.h)."""
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or cin % 16 or mb not in (1, 2) or cout % (16 * mb):
+        raise RuntimeError("conv_wino_prepare: 3x3 kernel, Cin %% 16 == 0 and Cout %% (16 * mb) == 0 required (got %s, mb=%d)"
+                           % (tuple(w.shape), mb))
+    g = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = (g @ w.double() @ g.t()).float()                       # [Cout, Cin, xi, nu]
+    #          ct               mb_i m   chunk     q  i  xi nu
+    v = u.reshape(cout // (16 * mb), mb, 16, cin // 16, 4, 4, 4, 4)
+    v = v.permute(0, 3, 5, 1, 6, 4, 2, 7)                      # -> [ct, chunk, i, mb_i, xi, q, m, nu]
+    return v.reshape(-1).contiguous()
+
+
+def conv_wino_ok(kernel, stride, cin, cout):
+    """Shapes smos_conv_wino_cl covers: 3x3, stride 1, "same" padding, Cin and Cout multiples of 16."""
+    return tuple(kernel) == (3, 3) and stride == 1 and cin % 16 == 0 and cout % 16 == 0
+
+
+def conv_wino_mb(cout, n_items16):
+    """16-channel output blocks per wave: 2 (less operand traffic per multiply-add) unless that leaves fewer work items than
+    resident blocks (2 per CU x 256 CUs); n_items16 = items at mb = 1."""
+    return 2 if cout % 32 == 0 and n_items16 // 2 >= 512 else 1
+
+
+def conv_wino_sum_chunks(h, w):
+    """Chunks per sample in the channel-sum table of conv_wino_cl(..., chan_sums=...)."""
+    return ((h + 7) // 8) * ((w + 31) // 32) * 4
+
+
+def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_sums=None):
+    """act(conv3x3(x) + bias [+ residual]) (stride 1, "same" padding) on channels-last [B,C,H,W] views in one launch of the
+    Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip).  wprep = conv_wino_prepare(w, mb).
+    chan_sums: optional float32 [B, conv_wino_sum_chunks(H, W), Cout]; not together with a residual."""
+    _require_cuda("conv_wino_cl", x, wprep, bias, residual, out, chan_sums)
+    b, cin, h, w = x.shape
+    if not conv_wino_ok((3, 3), 1, cin, cout) or mb not in (1, 2) or cout % (16 * mb) or wprep.numel() != 16 * cout * cin:
+        raise RuntimeError("conv_wino_cl: unsupported shape %s -> %d (mb=%d)" % (tuple(x.shape), cout, mb))
+    if out is None:
+        out = empty_cl(b, cout, h, w, x.device)
+    elif tuple(out.shape) != (b, cout, h, w):
+        raise RuntimeError("conv_wino_cl: out has shape %s" % (tuple(out.shape),))
+    if residual is not None and tuple(residual.shape) != (b, cout, h, w):
+        raise RuntimeError("conv_wino_cl: residual has shape %s" % (tuple(residual.shape),))
+    if chan_sums is not None and (residual is not None or not chan_sums.is_contiguous() or chan_sums.dtype != torch.float32 or
+                                  tuple(chan_sums.shape) != (b, conv_wino_sum_chunks(h, w), cout)):
+        raise RuntimeError("conv_wino_cl: chan_sums must be contiguous float32 [B, conv_wino_sum_chunks(H, W), Cout], without a residual")
+    lib = _lib.load()
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk3x3%s]" % (b, cin, h, w, cout, h, w, "+res" if residual is not None else "")
+    args = (x.data_ptr(), _cl("conv_wino_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None, _cl("conv_wino_cl", residual) if residual is not None else 0,
+            out.data_ptr(), _cl("conv_wino_cl", out), b, h, w, cin, cout, int(mb), int(act),
+            chan_sums.data_ptr() if chan_sums is not None else None)
+    with torch.cuda.device(x.device), profiling.span(label):
+        rc = lib.smos_conv_wino_cl(*args, _stream(x))
+    _lib.check(rc, "smos_conv_wino_cl")
+    if profiling._replay_label == label:
+        keep = (x, wprep, bias, residual, out, chan_sums)
+
+        def again(keep=keep):
+            with torch.cuda.device(keep[0].device), profiling.span(label):
+                _lib.check(lib.smos_conv_wino_cl(*args, _stream(keep[0])), "smos_conv_wino_cl")
+        profiling.offer_replay(label, again)
+    return out
+
+
 def msda_fwd_qp(value, qp, h, w, points):
     """value [N, H*W, M, 32] contiguous, qp [N, H*W, M*P*3] contiguous (offsets | logits) -> [N, H*W, M*32]."""
     _require_cuda("msda_fwd_qp", value, qp)

@@ -826,3 +826,104 @@ def test_pybind_name_msda_module_with_the_references_argument_lists(golden, bind
         MSDA.ms_deform_attn_forward(tv.cpu(), ts, ti, tl, ta, 2)
     with pytest.raises(RuntimeError):                                                   # batch % im2col_step
         MSDA.ms_deform_attn_forward(torch.cat((tv, tv, tv)), ts, ti, torch.cat((tl, tl, tl)), torch.cat((ta, ta, ta)), 2)
+
+
+_WINO_CASES = [
+    # cin, cout, (h, w), mb, act, residual
+    (32, 32, (40, 64), 2, 1, False),
+    (32, 32, (40, 64), 1, 1, True),
+    (64, 32, (24, 96), 2, 1, True),
+    (64, 64, (16, 32), 2, 1, False),
+    (128, 64, (16, 32), 2, 1, True),
+    (128, 128, (16, 64), 2, 1, True),
+    (128, 128, (16, 64), 1, 0, False),
+    (64, 128, (16, 64), 2, 2, False),
+    (128, 64, (16, 64), 2, 2, False),
+    (16, 16, (8, 32), 1, 1, False),             # one chunk, one item
+    (48, 48, (9, 33), 1, 2, True),              # Cin not a multiple of 32; one row / column past a block
+    (32, 32, (13, 45), 2, 2, True),             # odd sizes: half tiles at the right and bottom edges
+    (32, 64, (3, 8), 2, 1, False),              # smaller than one block
+    (32, 32, (1, 1), 2, 0, False),              # a single pixel
+    (32, 32, (70, 130), 2, 1, False),           # several blocks per image in both directions (items > resident blocks: no)
+]
+
+
+@pytest.mark.parametrize("cin,cout,hw,mb,act,with_res", _WINO_CASES)
+def test_conv_wino_cl_against_float64(cin, cout, hw, mb, act, with_res):
+    """csrc/conv_wino.hip (Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32, host-transformed weights, fused epilogue)
+    against conv2d in float64 and against the direct own conv; channel slices of wider buffers as operands.  Same bar as the
+    direct kernel (2e-5 of the output range; tools/winograd_numerics.py: 2e-7 .. 6e-7 expected)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(83)
+    b, (h, w) = 3, hw
+    wide = torch.randn((b, h, w, cin + 32), generator=gen).to(DEV)
+    x = wide[..., 32:].permute(0, 3, 1, 2)
+    res_wide = torch.randn((b, h, w, cout + 16), generator=gen).to(DEV)
+    res = res_wide[..., :cout].permute(0, 3, 1, 2) if with_res else None
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (cin * 9)) ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    out_wide = torch.full((b, h, w, cout + 8), 7.0, device=DEV)
+    out = out_wide[..., 4:4 + cout].permute(0, 3, 1, 2)
+    got = ops.conv_wino_cl(x, ops.conv_wino_prepare(wt, mb), bias, act, cout, mb=mb, residual=res, out=out)
+    want = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)
+    if with_res:
+        want = want + res.double()
+    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.01) if act == 2 else want)
+    err = (got.double() - want).abs().max().item() / want.abs().max().item()
+    print("wino %d->%d @%s mb %d: %.2e of range" % (cin, cout, hw, mb, err))
+    assert err <= 2e-5, err
+    assert bool((out_wide[..., :4] == 7.0).all()) and bool((out_wide[..., 4 + cout:] == 7.0).all())   # neighbours untouched
+    got2 = ops.conv_wino_cl(x, ops.conv_wino_prepare(wt, mb), None, 0, cout, mb=mb)
+    want2 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    assert (got2.double() - want2).abs().max().item() <= 2e-5 * want2.abs().max().item()
+    if cin % 32 == 0 and cout % 32 == 0:                                  # and the direct kernel next to it
+        direct = ops.conv_cl(x, ops.conv_prepare(wt, 1), None, 0, cout, (3, 3), mt=1)
+        assert (got2 - direct).abs().max().item() <= 4e-6 * want2.abs().max().item()
+
+
+def test_conv_wino_cl_is_deterministic_and_batch_independent():
+    gen = torch.Generator(device="cpu").manual_seed(89)
+    x = torch.randn((3, 64, 64, 64), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    wt = (torch.randn((64, 64, 3, 3), generator=gen) * 0.05).to(DEV)
+    wp = ops.conv_wino_prepare(wt, 2)
+    a = ops.conv_wino_cl(x, wp, None, 1, 64, mb=2)
+    b = ops.conv_wino_cl(x, wp, None, 1, 64, mb=2)
+    c = ops.conv_wino_cl(x[1:2], wp, None, 1, 64, mb=2)
+    assert torch.equal(a, b) and torch.equal(a[1:2], c)
+
+
+@pytest.mark.parametrize("cin,cout,hw,mb", [(32, 32, (40, 64), 2), (64, 64, (13, 45), 2), (128, 128, (16, 32), 1), (32, 32, (3, 8), 1)])
+def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb):
+    """conv_wino_cl(chan_sums=...): channel sums per (8-row x 32-column block, tile row) in a fixed order; the ChannelAtt gate
+    (networks/backbone.py:57-73, 87-102) built on them equals float64."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(97)
+    b, (h, w) = 3, hw
+    x = torch.randn((b, h, w, cin), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (cin * 9)) ** 0.5).to(DEV)
+    chunks = ops.conv_wino_sum_chunks(h, w)
+    sums = torch.full((b, chunks, cout), 7.0, device=DEV)
+    wp = ops.conv_wino_prepare(wt, mb)
+    y = ops.conv_wino_cl(x, wp, None, 0, cout, mb=mb, chan_sums=sums)
+    assert torch.equal(y, ops.conv_wino_cl(x, wp, None, 0, cout, mb=mb))            # the output itself is untouched
+    xb = (w + 31) // 32
+    want = torch.zeros((b, chunks, cout), dtype=torch.float64, device=DEV)
+    yd = y.double()
+    for yy in range(0, h, 2):
+        for t in range(xb):
+            want[:, ((yy // 8) * xb + t) * 4 + (yy % 8) // 2] = yd[:, :, yy:yy + 2, 32 * t:32 * t + 32].sum((2, 3))
+    scale = yd.abs().sum((2, 3)).max().item() / max(h // 2 * xb, 1)
+    assert (sums.double() - want).abs().max().item() <= 1e-5 * scale
+    sums2 = torch.empty_like(sums)
+    ops.conv_wino_cl(x, wp, None, 0, cout, mb=mb, chan_sums=sums2)
+    assert torch.equal(sums, sums2)                                                  # fixed summation order
+    cr = max(cout // 4, 8)
+    bias, b1, b2 = (torch.randn(n, generator=gen).to(DEV) for n in (cout, cr, cout))
+    w1 = (torch.randn((cr, cout), generator=gen) * 0.3).to(DEV)
+    w2 = (torch.randn((cout, cr), generator=gen) * 0.3).to(DEV)
+    xres = torch.randn((b, h, w, cout), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    got = ops.channel_gate_apply_cl(y, bias, w1, b1, w2, b2, xres, sums, torch.empty(b * cout, device=DEV))
+    z = yd + bias.double()[None, :, None, None]
+    g = torch.sigmoid(F.linear(F.relu(F.linear(z.mean((2, 3)), w1.double(), b1.double())), w2.double(), b2.double()))
+    ref = F.relu(z * g[:, :, None, None] + xres.double())
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
