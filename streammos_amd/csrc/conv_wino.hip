@@ -77,7 +77,7 @@ struct WinoItem {
 template <int MB, bool RES, bool SUMS>
 __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float4* w_lds = reinterpret_cast<float4*>(lds + 2 * kWInWords);       // two slots of 256 * MB float4
+  float4* w_lds = reinterpret_cast<float4*>(lds + 2 * kWInWords);       // three slots of 256 * MB float4
   constexpr int kSlot = 256 * MB;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,24 +113,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // ---- staging of a chunk's input region: thread = (pixel tid / 4 + 64 k, channel group tid % 4), k = 0..5 ----
   const int xp = (int)a.xp;
   const int sp0 = tid >> 2, sc4 = tid & 3;
-  u32x4 st0, st1, st2, st3, st4, st5;
+  u32x4 st0, st1, st2;
 #define WINO_STAGE_ONE(dst, k, t, c, valid)                                                                        \
   do {                                                                                                             \
-    const int p_ = sp0 + 64 * (k);                                                                                 \
+    int p_ = sp0 + 64 * (k);                                                                                       \
+    asm volatile("" : "+v"(p_));      /* opaque: (py, px) are recomputed here, not kept in 12 registers across the loop */ \
     const int py_ = (p_ * 241) >> 13, px_ = p_ - 34 * py_;          /* p / 34 for p < 384 */                       \
     const int gy_ = (t).y0 - 1 + py_, gx_ = (t).x0 - 1 + px_;                                                      \
     const bool ok_ = (valid) & (p_ < kWRegPix) & ((unsigned)gy_ < (unsigned)a.H) & ((unsigned)gx_ < (unsigned)a.W); \
     const unsigned off_ = ok_ ? (unsigned)((((t).b * a.H + gy_) * a.W + gx_) * xp + 16 * (c) + 4 * sc4) * 4u : 0x80000000u; \
     dst = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off_, 0, 0);                                                 \
   } while (0)
-#define WINO_STAGE_LOAD(t, c, valid)      \
+  // the region travels in two halves through the SAME three registers (rounds 0..2, then 3..5): 12 instead of 24 live
+#define WINO_STAGE_LOAD_A(t, c, valid)    \
   do {                                    \
     WINO_STAGE_ONE(st0, 0, t, c, valid);  \
     WINO_STAGE_ONE(st1, 1, t, c, valid);  \
     WINO_STAGE_ONE(st2, 2, t, c, valid);  \
-    WINO_STAGE_ONE(st3, 3, t, c, valid);  \
-    WINO_STAGE_ONE(st4, 4, t, c, valid);  \
-    WINO_STAGE_ONE(st5, 5, t, c, valid);  \
+  } while (0)
+#define WINO_STAGE_LOAD_B(t, c, valid)    \
+  do {                                    \
+    WINO_STAGE_ONE(st0, 3, t, c, valid);  \
+    WINO_STAGE_ONE(st1, 4, t, c, valid);  \
+    WINO_STAGE_ONE(st2, 5, t, c, valid);  \
   } while (0)
   // channel 4 c4 + i of pixel p goes to word p * 17 + 4 i + c4 (k-step i reads word 4 i + q)
 #define WINO_PARK_ONE(buf, src, k)                            \
@@ -141,29 +146,38 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     d_[8] = __uint_as_float(src.z);                           \
     d_[12] = __uint_as_float(src.w);                          \
   } while (0)
-#define WINO_STAGE_WRITE(buf)                                 \
+#define WINO_STAGE_WRITE_A(buf)                               \
   do {                                                        \
     WINO_PARK_ONE(buf, st0, 0);                               \
     WINO_PARK_ONE(buf, st1, 1);                               \
     WINO_PARK_ONE(buf, st2, 2);                               \
-    WINO_PARK_ONE(buf, st3, 3);                               \
-    WINO_PARK_ONE(buf, st4, 4);                               \
-    if (sp0 + 320 < kWRegPix) WINO_PARK_ONE(buf, st5, 5);     \
+  } while (0)
+#define WINO_STAGE_WRITE_B(buf)                               \
+  do {                                                        \
+    WINO_PARK_ONE(buf, st0, 3);                               \
+    WINO_PARK_ONE(buf, st1, 4);                               \
+    if (sp0 + 320 < kWRegPix) WINO_PARK_ONE(buf, st2, 5);     \
   } while (0)
 
-  // ---- weights: the slice of k-step (ct, c, i) is 256 * MB consecutive float4 ----
-  float4 wr0, wr1;
-#define WINO_W_LOAD(ct, c, i)                                                                            \
-  do {                                                                                                   \
-    const float4* s_ = a.w + (int64_t)((((ct) * a.nchunk + (c)) << 2) + (i)) * kSlot + tid;               \
-    wr0 = s_[0];                                                                                         \
-    if constexpr (MB > 1) wr1 = s_[256];                                                                 \
+  // ---- weights: the slices of consecutive k-steps are consecutive, cyclically over the block's items (cout tile fastest).
+  // They travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write; a wave's 64 lanes fill 1 KB
+  // of the slot, which is exactly the slice's lane-linear layout): the slice of k-step s + 2 is requested at the head of
+  // k-step s into ring slot (s + 2) % 3.  hipcc does not count LDS-DMA against LDS reads, so the wait is explicit: before the
+  // barrier that ends k-step s, everything but the requests issued during k-step s itself has landed (vmcnt retires in
+  // order), i.e. the slice k-step s + 1 reads ----
+  const int n_slices = a.nct * a.nchunk * 4;
+  int pa_slice = (first % a.nct) * a.nchunk * 4;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+#define WINO_W_LOAD(so)                                                                                          \
+  do {                                                                                                           \
+    const float4* s_ = a.w + (int64_t)__builtin_amdgcn_readfirstlane(pa_slice) * kSlot + tid;                     \
+    float4* d_ = w_lds + (so) + wave * 64;                                                                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)d_, 16, 0, 0);                                          \
+    if constexpr (MB > 1) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + 256), (lptr_t)(d_ + 256), 16, 0, 0);    \
+    pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;                                                      \
   } while (0)
-#define WINO_W_WRITE(slot)                                        \
-  do {                                                            \
-    w_lds[(slot) * kSlot + tid] = wr0;                            \
-    if constexpr (MB > 1) w_lds[(slot) * kSlot + 256 + tid] = wr1; \
-  } while (0)
+#define WINO_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
 
   f32x4 acc[MB][16];
 #pragma unroll
@@ -174,36 +188,93 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // this lane's patch origin inside a region buffer: tile (row = wave, column = tx) -> region pixel (2 wave, 2 tx), word q
   const int in_base = ((2 * wave) * kWRegW + 2 * tx) * kWPP + q;
 
-  // ---- one k-step: patch -> B^T d B -> 16 x MB x ... MFMAs ----
-#define WINO_KSTEP(buf, i, slot)                                                                                   \
-  do {                                                                                                             \
-    const float* pin_ = (buf) + in_base + 4 * (i);                                                                 \
-    float d_[16];                                                                                                  \
-    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                               \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) d_[4 * r_ + c_] = pin_[(r_ * kWRegW + c_) * kWPP];         \
-    float t_[16], v_[16];                                                                                          \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                             \
-      t_[c_] = d_[c_] - d_[8 + c_];                                                                                \
-      t_[4 + c_] = d_[4 + c_] + d_[8 + c_];                                                                        \
-      t_[8 + c_] = d_[8 + c_] - d_[4 + c_];                                                                        \
-      t_[12 + c_] = d_[4 + c_] - d_[12 + c_];                                                                      \
-    }                                                                                                              \
-    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                             \
-      v_[4 * r_] = t_[4 * r_] - t_[4 * r_ + 2];                                                                    \
-      v_[4 * r_ + 1] = t_[4 * r_ + 1] + t_[4 * r_ + 2];                                                            \
-      v_[4 * r_ + 2] = t_[4 * r_ + 2] - t_[4 * r_ + 1];                                                            \
-      v_[4 * r_ + 3] = t_[4 * r_ + 1] - t_[4 * r_ + 3];                                                            \
-    }                                                                                                              \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                             \
-      float4 af_[MB];                                                                                              \
-      _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) af_[mb_] = w_lds[(slot) * kSlot + (mb_ * 4 + g_) * 64 + lane]; \
-      _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) {                                                       \
-        acc[mb_][4 * g_ + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].x, v_[4 * g_ + 0], acc[mb_][4 * g_ + 0], 0, 0, 0); \
-        acc[mb_][4 * g_ + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].y, v_[4 * g_ + 1], acc[mb_][4 * g_ + 1], 0, 0, 0); \
-        acc[mb_][4 * g_ + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].z, v_[4 * g_ + 2], acc[mb_][4 * g_ + 2], 0, 0, 0); \
-        acc[mb_][4 * g_ + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[mb_].w, v_[4 * g_ + 3], acc[mb_][4 * g_ + 3], 0, 0, 0); \
-      }                                                                                                            \
-    }                                                                                                              \
+  // ---- pieces of a k-step ----
+  float va[16], vb[16];                  // B operands of the current / next k-step (the next patch is transformed in place)
+  float4 afa[MB], afb[MB];               // A operands of two consecutive (xi) groups
+#define WINO_D_READ(v, buf, i)                                                                          \
+  do {                                                                                                  \
+    const float* pin_ = (buf) + in_base + 4 * (i);                                                      \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                    \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v[4 * r_ + c_] = pin_[(r_ * kWRegW + c_) * kWPP]; \
+  } while (0)
+  // B^T d (rows), in place: row 0 <- d0 - d2, 1 <- d1 + d2, 2 <- d2 - d1, 3 <- d1 - d3
+#define WINO_T_ROWS(v)                                         \
+  do {                                                         \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {         \
+      const float d0_ = v[c_], d1_ = v[4 + c_], d2_ = v[8 + c_], d3_ = v[12 + c_]; \
+      v[c_] = d0_ - d2_;                                       \
+      v[4 + c_] = d1_ + d2_;                                   \
+      v[8 + c_] = d2_ - d1_;                                   \
+      v[12 + c_] = d1_ - d3_;                                  \
+    }                                                          \
+  } while (0)
+  // (B^T d) B (columns), in place -> the 16 B operands
+#define WINO_T_COLS(v)                                         \
+  do {                                                         \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {         \
+      const float t0_ = v[4 * r_], t1_ = v[4 * r_ + 1], t2_ = v[4 * r_ + 2], t3_ = v[4 * r_ + 3]; \
+      v[4 * r_] = t0_ - t2_;                                   \
+      v[4 * r_ + 1] = t1_ + t2_;                               \
+      v[4 * r_ + 2] = t2_ - t1_;                               \
+      v[4 * r_ + 3] = t1_ - t3_;                               \
+    }                                                          \
+  } while (0)
+#define WINO_A_READ(af, so, g)                                                                          \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) af[mb_] = w_lds[(so) + (mb_ * 4 + (g)) * 64 + lane]; \
+  } while (0)
+  // the MFMAs of one (xi) group for m-block mb: nu = 0..3
+#define WINO_MFMA4(v, af, g, mb_)                                                                                             \
+  do {                                                                                                                        \
+    acc[mb_][4 * (g) + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb_].x, v[4 * (g) + 0], acc[mb_][4 * (g) + 0], 0, 0, 0);  \
+    acc[mb_][4 * (g) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb_].y, v[4 * (g) + 1], acc[mb_][4 * (g) + 1], 0, 0, 0);  \
+    acc[mb_][4 * (g) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb_].z, v[4 * (g) + 2], acc[mb_][4 * (g) + 2], 0, 0, 0);  \
+    acc[mb_][4 * (g) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb_].w, v[4 * (g) + 3], acc[mb_][4 * (g) + 3], 0, 0, 0);  \
+  } while (0)
+#define WINO_MFMA_GROUP(v, af, g)                                            \
+  do {                                                                       \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) WINO_MFMA4(v, af, g, mb_); \
+  } while (0)
+
+  // ---- one k-step.  v: B operands of this k-step (ready); vn: receives those of the next one, whose patch is read from
+  //      (nbuf, channel ni); so0 / so1 / so2: ring slots (float4 offsets) of this k-step, the next one and the one the slice
+  //      requested here is parked in; head / tail: extra pieces (region requests / region stores).  afa holds group 0 of this
+  //      k-step on entry and of the next one on exit; the slots rotate at the end. ----
+#define WINO_KSTEP(v, vn, nbuf, ni, HEAD, TAIL, NVM)                   \
+  do {                                                                 \
+    WINO_A_READ(afb, so0, 1);                                          \
+    WINO_W_LOAD(so2);                                                  \
+    HEAD;                                                              \
+    WINO_D_READ(vn, nbuf, ni);                                         \
+    SMOS_FENCE();                                                      \
+    WINO_MFMA_GROUP(v, afa, 0);                                        \
+    SMOS_FENCE();                                                      \
+    WINO_A_READ(afa, so0, 2);                                          \
+    WINO_T_ROWS(vn);                                                   \
+    SMOS_FENCE();                                                      \
+    WINO_MFMA_GROUP(v, afb, 1);                                        \
+    SMOS_FENCE();                                                      \
+    WINO_A_READ(afb, so0, 3);                                          \
+    WINO_T_COLS(vn);                                                   \
+    SMOS_FENCE();                                                      \
+    WINO_MFMA_GROUP(v, afa, 2);                                        \
+    SMOS_FENCE();                                                      \
+    TAIL;                                                              \
+    SMOS_FENCE();                                                      \
+    WINO_MFMA4(v, afb, 3, 0);                                          \
+    SMOS_FENCE();                                                      \
+    WINO_VM_WAIT(NVM);                                                 \
+    ring_barrier();                                                    \
+    WINO_A_READ(afa, so1, 0);                                          \
+    SMOS_FENCE();                                                      \
+    if constexpr (MB > 1) WINO_MFMA4(v, afb, 3, MB - 1);               \
+    SMOS_FENCE();                                                      \
+    {                                                                  \
+      const int r_ = so0;                                              \
+      so0 = so1;                                                       \
+      so1 = so2;                                                       \
+      so2 = r_;                                                        \
+    }                                                                  \
   } while (0)
 
   // ---- epilogue of an item: A^T M A per (cout, tile) in the lane, bias / residual / activation, 16-byte stores ----
@@ -271,13 +342,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     }
   };
 
-  // ---- prologue: region of chunk 0 in buffer 0, weights of k-step 0 in slot 0 ----
+  // ---- prologue: region of chunk 0 in buffer 0, slices 0 and 1 in slots 0 and 1, B operands of k-step 0 ----
   WinoItem cur = item_of(0);
-  WINO_STAGE_LOAD(cur, 0, true);
-  WINO_W_LOAD(cur.ct, 0, 0);
-  WINO_STAGE_WRITE(lds);
-  WINO_W_WRITE(0);
+  int so0 = 0, so1 = kSlot, so2 = 2 * kSlot;
+  WINO_STAGE_LOAD_A(cur, 0, true);
+  WINO_W_LOAD(so0);
+  WINO_W_LOAD(so1);
+  WINO_STAGE_WRITE_A(lds);
+  WINO_STAGE_LOAD_B(cur, 0, true);
+  WINO_STAGE_WRITE_B(lds);
+  WINO_VM_WAIT(0);
   ring_barrier();
+  WINO_D_READ(va, lds, 0);
+  WINO_T_ROWS(va);
+  WINO_T_COLS(va);
+  WINO_A_READ(afa, so0, 0);
 
   int it = 0, c = 0;
   float* buf_cur = lds;
@@ -290,24 +369,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
       it_n = it + 1;
     }
     const WinoItem nxt = c_n == 0 ? item_of(it_n) : cur;           // past the last item: clamped, loads masked off
-    WINO_STAGE_LOAD(nxt, c_n, g + 1 < total);
-    WINO_W_LOAD(cur.ct, c, 1);
-    WINO_KSTEP(buf_cur, 0, 0);
-    WINO_W_WRITE(1);
-    ring_barrier();
-    WINO_W_LOAD(cur.ct, c, 2);
-    WINO_KSTEP(buf_cur, 1, 1);
-    WINO_W_WRITE(0);
-    ring_barrier();
-    WINO_W_LOAD(cur.ct, c, 3);
-    WINO_KSTEP(buf_cur, 2, 0);
-    WINO_W_WRITE(1);
-    ring_barrier();
-    WINO_W_LOAD(nxt.ct, c_n, 0);
-    WINO_KSTEP(buf_cur, 3, 1);
-    WINO_W_WRITE(0);
-    WINO_STAGE_WRITE(buf_nxt);
-    ring_barrier();
+    const bool more = g + 1 < total;
+    // The next chunk's region: first half requested at the head of k-step 0 and stored at the tail of k-step 1, second half
+    // requested right behind that store and stored at the tail of k-step 2; the barrier that ends k-step 2 publishes the
+    // buffer, so that k-step 3 can already read the first patch of the next chunk.
+    // (last argument: the VMEM requests a wave issues in the k-step itself -- its own weight DMA and region requests -- i.e.
+    // what may still be in flight at the k-step's barrier)
+    WINO_KSTEP(va, vb, buf_cur, 1, WINO_STAGE_LOAD_A(nxt, c_n, more), (void)0, MB + 3);
+    WINO_KSTEP(vb, va, buf_cur, 2, (void)0, WINO_STAGE_WRITE_A(buf_nxt); WINO_STAGE_LOAD_B(nxt, c_n, more), MB + 3);
+    WINO_KSTEP(va, vb, buf_cur, 3, (void)0, WINO_STAGE_WRITE_B(buf_nxt), MB);
+    WINO_KSTEP(vb, va, buf_nxt, 0, (void)0, (void)0, MB);
     if (c_n == 0) {
       epilogue(cur);
       cur = nxt;
@@ -326,7 +397,7 @@ using namespace smos;
 
 template <int MB, bool RES, bool SUMS>
 static int launch_wino(const WinoArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * kWInWords * sizeof(float) + (size_t)2 * 256 * MB * sizeof(float4);
+  const size_t lds = (size_t)2 * kWInWords * sizeof(float) + (size_t)3 * 256 * MB * sizeof(float4);
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_wino<MB, RES, SUMS>), lds, 256, &ks, "conv_wino_cl")) return rc;
   static const int want_per_cu = [] {
