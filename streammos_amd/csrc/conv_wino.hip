@@ -35,6 +35,15 @@
 
 #include "conv_common.h"
 
+// Diagnostic builds only (tools/ablate_wino.sh): -DSMOS_WINO_ABLATE=<bits> removes one ingredient at a time (1 region
+// requests, 2 region stores, 4 weight DMA, 8 barrier, 16 patch reads + transform, 32 A-operand reads, 64 output stores,
+// 128 the explicit vmcnt wait) to time what is left; results are wrong.  The shipped library is built without it.
+#ifdef SMOS_WINO_ABLATE
+#define WINO_AB(bit) ((SMOS_WINO_ABLATE) & (bit))
+#else
+#define WINO_AB(bit) 0
+#endif
+
 namespace smos {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     const int gy_ = (t).y0 - 1 + py_, gx_ = (t).x0 - 1 + px_;                                                      \
     const bool ok_ = (valid) & (p_ < kWRegPix) & ((unsigned)gy_ < (unsigned)a.H) & ((unsigned)gx_ < (unsigned)a.W); \
     const unsigned off_ = ok_ ? (unsigned)((((t).b * a.H + gy_) * a.W + gx_) * xp + 16 * (c) + 4 * sc4) * 4u : 0x80000000u; \
-    dst = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off_, 0, 0);                                                 \
+    if (WINO_AB(1)) dst = u32x4{off_, 0u, 0u, 0u};                                                                 \
+    else dst = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off_, 0, 0);                                            \
   } while (0)
   // the region travels in two halves through the SAME three registers (rounds 0..2, then 3..5): 12 instead of 24 live
 #define WINO_STAGE_LOAD_A(t, c, valid)    \
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
 #define WINO_PARK_ONE(buf, src, k)                            \
   do {                                                        \
     float* d_ = (buf) + (sp0 + 64 * (k)) * kWPP + sc4;        \
+    if (WINO_AB(2) && src.x != 0x7fc12345u) break;            \
     d_[0] = __uint_as_float(src.x);                           \
     d_[4] = __uint_as_float(src.y);                           \
     d_[8] = __uint_as_float(src.z);                           \
@@ -173,11 +184,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   do {                                                                                                           \
     const float4* s_ = a.w + (int64_t)__builtin_amdgcn_readfirstlane(pa_slice) * kSlot + tid;                     \
     float4* d_ = w_lds + (so) + wave * 64;                                                                       \
-    __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)d_, 16, 0, 0);                                          \
-    if constexpr (MB > 1) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + 256), (lptr_t)(d_ + 256), 16, 0, 0);    \
+    if (!WINO_AB(4)) {                                                                                           \
+      __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)d_, 16, 0, 0);                                        \
+      if constexpr (MB > 1) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + 256), (lptr_t)(d_ + 256), 16, 0, 0);  \
+    }                                                                                                            \
     pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;                                                      \
   } while (0)
-#define WINO_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
+#define WINO_VM_WAIT(n)                                                   \
+  do {                                                                    \
+    if (!WINO_AB(128)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory"); \
+  } while (0)
+#define WINO_BARRIER()                                   \
+  do {                                                   \
+    if (WINO_AB(8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    else ring_barrier();                                 \
+  } while (0)
 
   f32x4 acc[MB][16];
 #pragma unroll
@@ -191,8 +212,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // ---- pieces of a k-step ----
   float va[16], vb[16];                  // B operands of the current / next k-step (the next patch is transformed in place)
   float4 afa[MB], afb[MB];               // A operands of two consecutive (xi) groups
+#ifdef SMOS_WINO_ABLATE
+  for (int k = 0; k < 16; ++k) va[k] = vb[k] = (float)(lane + k);
+  for (int k = 0; k < MB; ++k) afa[k] = afb[k] = make_float4((float)lane, 1.f, 2.f, (float)k);
+#endif
 #define WINO_D_READ(v, buf, i)                                                                          \
   do {                                                                                                  \
+    if (WINO_AB(16)) break;                                                                             \
     const float* pin_ = (buf) + in_base + 4 * (i);                                                      \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                    \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v[4 * r_ + c_] = pin_[(r_ * kWRegW + c_) * kWPP]; \
@@ -200,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // B^T d (rows), in place: row 0 <- d0 - d2, 1 <- d1 + d2, 2 <- d2 - d1, 3 <- d1 - d3
 #define WINO_T_ROWS(v)                                         \
   do {                                                         \
+    if (WINO_AB(16)) break;                                    \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {         \
       const float d0_ = v[c_], d1_ = v[4 + c_], d2_ = v[8 + c_], d3_ = v[12 + c_]; \
       v[c_] = d0_ - d2_;                                       \
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // (B^T d) B (columns), in place -> the 16 B operands
 #define WINO_T_COLS(v)                                         \
   do {                                                         \
+    if (WINO_AB(16)) break;                                    \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {         \
       const float t0_ = v[4 * r_], t1_ = v[4 * r_ + 1], t2_ = v[4 * r_ + 2], t3_ = v[4 * r_ + 3]; \
       v[4 * r_] = t0_ - t2_;                                   \
@@ -221,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   } while (0)
 #define WINO_A_READ(af, so, g)                                                                          \
   do {                                                                                                  \
+    if (WINO_AB(32)) break;                                                                             \
     _Pragma("unroll") for (int mb_ = 0; mb_ < MB; ++mb_) af[mb_] = w_lds[(so) + (mb_ * 4 + (g)) * 64 + lane]; \
   } while (0)
   // the MFMAs of one (xi) group for m-block mb: nu = 0..3
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     WINO_MFMA4(v, afb, 3, 0);                                          \
     SMOS_FENCE();                                                      \
     WINO_VM_WAIT(NVM);                                                 \
-    ring_barrier();                                                    \
+    WINO_BARRIER();                                                    \
     WINO_A_READ(afa, so1, 0);                                          \
     SMOS_FENCE();                                                      \
     if constexpr (MB > 1) WINO_MFMA4(v, afb, 3, MB - 1);               \
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
           ov[e] = __float_as_uint(o);
           if constexpr (SUMS) ssum[e] += ok[k] ? o : 0.f;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff[k], 0, 0);
+        if (!WINO_AB(64) || ov.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff[k], 0, 0);
       }
       if constexpr (SUMS) {
         float4 sv;

@@ -154,6 +154,7 @@ class InferenceEngine:
         self.conv_rows_mt = int(os.environ.get("SMOS_CONV_ROWS_MT", "1"))      # largest mt the row-staging conv is used for
         self.conv_rows = int(os.environ.get("SMOS_CONV_ROWS", "3"))      # n > 0: row-staging conv for KW >= n at mt = 1; 0: off
         self.fused_gate_sums = os.environ.get("SMOS_GATE_SUMS", "1") != "0"      # ChannelAtt pool sums from the conv epilogue
+        self.wino = os.environ.get("SMOS_WINO", "1") != "0"      # Winograd F(2x2,3x3) for the stride-1 3x3 layers (A/B switch)
         self._wprep = {}
         self._shapes = None
         self._lsi = None
@@ -378,6 +379,16 @@ class InferenceEngine:
             return ops.bias_act_cl(y, bias, act, out=out if out is not None else y, residual=residual)
         b, _, h, wd = x.shape
         ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (wd + 2 * (kw // 2) - kw) // stride + 1
+        if self.wino and ops.conv_wino_ok((kh, kw), stride, cin, cout):
+            # stride-1 3x3: Winograd F(2x2, 3x3) on the matrix cores (csrc/conv_wino.hip): 4 instead of 9 multiply-adds per
+            # output and channel pair, fp32 throughout (weights transformed in float64 on the host); 1.35-1.7x the direct
+            # kernels per layer (tools/ubench_wino.py), logits within 2e-6 of the reference's (tests/test_gpu_e2e.py)
+            mb = ops.conv_wino_mb(cout, b * ((h + 7) // 8) * ((wd + 31) // 32) * (cout // 16))
+            key = (w.data_ptr(), "wino", mb)
+            wp = self._wprep.get(key)
+            if wp is None:
+                wp = self._wprep[key] = ops.conv_wino_prepare(w, mb)
+            return ops.conv_wino_cl(x, wp, bias, act, cout, mb=mb, residual=residual, out=out, chan_sums=chan_sums)
         mt = ops.conv_mt(cout, b * ho * wo, residual is not None)
         if self.conv_rows and mt <= self.conv_rows_mt and ops.conv_rows_ok((kh, kw), stride, cin, cout) and kw >= self.conv_rows:
             # the row-staging variant (csrc/conv_rows.hip): per layer within 0 .. -5 % of conv_igemm alone on the GPU, +1 % in the
@@ -411,7 +422,8 @@ class InferenceEngine:
         if (self.own_conv and self.fused_gate_sums and c % 32 == 0 and c <= 256 and 1024 % c == 0 and
                 ops.conv_cl_supported(y, c, tuple(p.w2.shape[2:]))):
             # the conv's epilogue leaves the per-row-segment channel sums behind: no pass over y2 for the average pool
-            chunks = ops.conv_sum_chunks(h, w)
+            wino = self.wino and ops.conv_wino_ok(tuple(p.w2.shape[2:]), 1, c, c)
+            chunks = ops.conv_wino_sum_chunks(h, w) if wino else ops.conv_sum_chunks(h, w)
             ws = self._block_ws(p, bsz * c * (chunks + 1))
             sums = ws[:bsz * chunks * c].view(bsz, chunks, c)
             y2 = self._conv(y, p.w2, None, NONE, chan_sums=sums)

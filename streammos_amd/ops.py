@@ -626,10 +626,10 @@ def conv_wino_ok(kernel, stride, cin, cout):
     return tuple(kernel) == (3, 3) and stride == 1 and cin % 16 == 0 and cout % 16 == 0
 
 
-def conv_wino_mb(cout, n_items16):
-    """16-channel output blocks per wave: 2 (less operand traffic per multiply-add) unless that leaves fewer work items than
-    resident blocks (2 per CU x 256 CUs); n_items16 = items at mb = 1."""
-    return 2 if cout % 32 == 0 and n_items16 // 2 >= 512 else 1
+def conv_wino_mb(cout, n_items16=None):
+    """16-channel output blocks per wave: 2 wherever Cout allows it -- half the operand traffic per multiply-add, and faster
+    on every layer of the network, the ones with fewer items than resident blocks included (tools/ubench_wino.py)."""
+    return 2 if cout % 32 == 0 else 1
 
 
 def conv_wino_sum_chunks(h, w):
