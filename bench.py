@@ -120,23 +120,30 @@ def algorithmic_flops(label, ctx=None):
 
 
 def executed_flops(engine, b, n, t, stem_class_rows):
-    """FLOPs the engine really executes for one scan (batch of b TTA samples, n padded points, t stacked scans):
-    walks the engine's own folded weights.  Differs from the reference's dense count (0.53 TFLOP) by the
-    sparse first stage (only occupied cells, only the taps their parity class feeds) and by conv_1 running as a direct
-    conv on the fine map + tap GEMMs of the coarse maps at their own resolution."""
+    """FLOPs the engine really executes on the matrix cores for one scan (batch of b TTA samples, n padded points, t stacked
+    scans): walks the engine's own folded weights.  Differs from the reference's dense count (0.53 TFLOP) by the
+    sparse first stage (only occupied cells, only the taps their parity class feeds), by conv_1 running as a conv on the fine
+    map + tap GEMMs of the coarse maps at their own resolution, and by the stride-1 3x3 layers running in the Winograd
+    F(2x2, 3x3) form (4 instead of 9 multiply-adds per output and channel pair)."""
     hb, wb = engine.bev_hw
     total = 2.0 * b * t * n * (8 * 64 + 64 * 64)                                # point MLP
     total += sum(2.0 * r * 192 * 32 * (taps + 1) for r, taps in zip(stem_class_rows, (1, 2, 2, 4)))   # sparse stem
 
-    def conv(w, px):
-        return 2.0 * b * px * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+    wino = getattr(engine, "wino", False)
+
+    def conv(w, px, stride=1):
+        # stride-1 3x3 layers run in the Winograd F(2x2, 3x3) form (csrc/conv_wino.hip): 16 multiply-adds per 2x2 outputs and
+        # channel pair = 4 per output instead of 9 (the transforms are additions on the vector unit and are not counted)
+        taps = 4 if (wino and stride == 1 and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0) \
+            else w.shape[2] * w.shape[3]
+        return 2.0 * b * px * w.shape[0] * w.shape[1] * taps
 
     def stage(blocks, h, w, first_sparse=False):
         nonlocal total
         for i, p in enumerate(blocks):
             if p.kind == "down":
                 if not (first_sparse and i == 0):
-                    total += conv(p.wa, (h // p.stride) * (w // p.stride)) + conv(p.wp, h * w)
+                    total += conv(p.wa, (h // p.stride) * (w // p.stride), p.stride) + conv(p.wp, h * w)
                 h, w = h // p.stride, w // p.stride
             elif p.kind == "unbalance":
                 total += conv(p.wa, h * w) + conv(p.wb, h * w) + conv(p.wc, h * w)
@@ -159,7 +166,7 @@ def executed_flops(engine, b, n, t, stem_class_rows):
     c0, cc1, cc2 = engine.conv_1a.shape[1], engine.conv_1z[0].cin, engine.conv_1z[1].cin
     co = engine.conv_1a.shape[0]
     if engine.upconv:
-        total += 2.0 * b * (h0 * w0 * 9 * c0 * co + h1 * w1 * 9 * cc1 * co + h2 * w2 * 9 * cc2 * co)
+        total += conv(engine.conv_1a, h0 * w0) + 2.0 * b * (h1 * w1 * 9 * cc1 * co + h2 * w2 * 9 * cc2 * co)
     else:
         total += 2.0 * b * h0 * w0 * 9 * (c0 + cc1 + cc2) * co
     total += conv(engine.conv_2[0], h0 * w0)

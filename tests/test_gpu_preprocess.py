@@ -48,7 +48,8 @@ def test_device_preprocess_matches_host(beams, azimuth, npad):
 
 def test_step_raw_equals_host_preprocessed_step():
     """StreamRunner.step_raw (device preprocessing) against step() on host-preprocessed inputs: same labels for the
-    raw scan except where a 1-ulp angle difference moves a point across a range-image cell (< 0.1 %)."""
+    raw scan except where a 1-ulp angle difference moves a point across a range-image cell (observed on MI355X: logits
+    4e-6 .. 1.6e-5 of the range, no label flipped; bars ~10x that, one flipped label of 2048 = 4.9e-4)."""
     from streammos_amd import streaming
     from streammos_amd.refapi.config import StreamMOS as cfg
     from streammos_amd.refapi.models import StreamMOS
@@ -68,10 +69,10 @@ def test_step_raw_equals_host_preprocessed_step():
         err = (oa["pred_cls"] - ob["pred_cls"]).abs().max().item() / oa["pred_cls"].abs().max().item()
         same = (oa["raw_labels"] == ob["raw_labels"]).float().mean().item()
         print("step_raw vs host-preprocessed step, frame %d: logits %.2e of range, raw labels %.6f" % (i, err, same))
-        assert err <= 2e-3 and same >= 0.999, (i, err, same)
+        assert err <= 2e-4 and same >= 0.9995, (i, err, same)
         assert [f for f, _ in oa["voted"]] == [f for f, _ in ob["voted"]]
         for (_, la), (_, lb) in zip(oa["voted"], ob["voted"]):
-            assert (la == lb).float().mean().item() >= 0.999
+            assert (la == lb).float().mean().item() >= 0.9995
 
 
 def test_step_raw_with_look_ahead_equals_plain_step_raw():
