@@ -73,6 +73,15 @@ def algorithmic_bytes(label, ctx=None):
     if name == "point_head":
         b, n = (int(v) for v in dims.split("x"))
         return 4 * b * n * (192 + 3)
+    if name == "upconv_xpass":
+        # tap products z [B, Hs, Ws, 9 C] in, x-interpolated rows t [B, 3, Hs, Wo, C] out (csrc/upconv.hip)
+        src, wo = dims.split("->")
+        b, hs, ws, c = (int(v) for v in src.split("x"))
+        return 4 * (b * hs * ws * 9 * c + b * 3 * hs * int(wo) * c)
+    if name == "upconv_ypass":
+        # direct-conv part in, the two sources' x-pass rows in (the network's geometry: half and quarter height), map out
+        b, ho, wo, c = (int(v) for v in dims.split("x"))
+        return 4 * (2 * b * ho * wo * c + b * 3 * (ho // 2 + ho // 4) * wo * c)
     if name == "conv_cl":
         # own implicit-GEMM conv (csrc/conv_igemm.hip): label B x Cin x H x W -> Cout x Ho x Wo k KHxKW [+res]
         geo = _conv_geometry(dims)
@@ -505,6 +514,7 @@ def main():
                                                "vector peak; dense_equivalent = the reference's 0.53 TFLOP/scan x scans/s, kept for "
                                                "comparison only (the sparse first stage and the restructured conv_1 skip work)"}),
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
+            "stem_rows_per_launch": None if ctx.get("stem_rows") is None else round(ctx["stem_rows"]),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if world == 1 and not args.no_raw:

@@ -1,0 +1,66 @@
+"""Per-LABEL kernel durations of one steady-state step (the kernel-stats CSVs aggregate by kernel
+template, so the bench line's dominant label could not be read off them).
+
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-raw \
+        --no-pipeline --label-log labels.json            (one stream: dispatch order = launch order)
+    python profiles/label_durations.py <kernel_trace.csv> labels.json [bench_line.json] > profiles/rNN_label_durations.csv
+
+Columns: label (or the kernel name for launches without one), launches per step, mean us per launch, algorithmic FLOPs and
+bytes per launch (bench.algorithmic_flops / algorithmic_bytes), bound, achieved, frac of the roof (157.3 TFLOP/s fp32 MFMA /
+8 TB/s HBM).  The bench line's roofline.frac for the dominant label must agree with this file's row within 5 %.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kinds  # noqa: E402
+
+import bench  # noqa: E402
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+labels = json.load(open(sys.argv[2]))
+ctx = {}
+if len(sys.argv) > 3:
+    try:
+        line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+        if line.get("stem_rows_per_launch") is not None:
+            ctx["stem_rows"] = line["stem_rows_per_launch"]
+    except (OSError, ValueError, IndexError):
+        pass
+step = kinds.steady_step(rows, key=lambda r: int(r["Start_Timestamp"]))
+pairs, problems = kinds.match(step, labels)
+for p in problems:
+    sys.stderr.write("label_durations: %s -- left unlabelled\n" % p)
+agg = collections.OrderedDict()
+for label, disp in pairs:
+    name = label if label else disp[0]["Kernel_Name"].split("(")[0][:90]
+    d = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in disp) / 1e3
+    a = agg.setdefault(name, [0, 0.0, label is not None])
+    a[0] += 1
+    a[1] += d
+w = csv.writer(sys.stdout)
+w.writerow(["label", "launches_per_step", "mean_us", "total_us", "alg_flops", "alg_bytes", "bound", "achieved", "unit", "frac"])
+total = 0.0
+for name, (n, us, labelled) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    total += us
+    mean = us / n
+    fl = by = 0
+    if labelled:
+        try:
+            fl, by = bench.algorithmic_flops(name, ctx), bench.algorithmic_bytes(name, ctx)
+        except (ValueError, KeyError, IndexError):
+            pass
+    t_m, t_h = fl / (bench.FP32_PEAK_TFLOPS * 1e12), by / (bench.HBM_PEAK_GBS * 1e9)
+    if fl and t_m > t_h:
+        ach = fl / (mean * 1e-6) / 1e12
+        w.writerow([name, n, "%.2f" % mean, "%.1f" % us, fl, by, "mfma", "%.1f" % ach, "TFLOP/s", "%.4f" % (ach / bench.FP32_PEAK_TFLOPS)])
+    elif by:
+        ach = by / (mean * 1e-6) / 1e9
+        w.writerow([name, n, "%.2f" % mean, "%.1f" % us, fl, by, "hbm", "%.1f" % ach, "GB/s", "%.4f" % (ach / bench.HBM_PEAK_GBS)])
+    else:
+        w.writerow([name, n, "%.2f" % mean, "%.1f" % us, "", "", "", "", "", ""])
+w.writerow(["# kernels of the step: %d, summed %.1f us" % (len(step), total)])

@@ -15,31 +15,27 @@ import csv
 import json
 import sys
 
-# kernel-name fragment -> label prefix, for the kernels that carry a one-launch profiling span in ops.py
-KIND = ((("conv_igemm", "conv_rows"), "conv_cl["), ("gather_scatter_cl", "gather_scatter_cl["), ("pointnet_scatter", "pointnet_scatter["),
-        ("point_head", "point_head["), ("stem_gemm", "stem_gemm["), ("stem_epilogue", "stem_epilogue["))
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kinds  # noqa: E402
+
 LABELS = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else []
 
 
 def per_label(path, counter):
     """Mean counter value per launch label.  The dispatches of ONE steady-state step (between the last two tta_argmax
     launches of a --no-pipeline run: one stream, dispatch order = launch order) are matched, kind by kind and in order,
-    with the labels bench.py --label-log recorded for a step."""
+    with the labels bench.py --label-log recorded for a step (profiles/kinds.py); a label that covers several dispatches
+    gets their sum."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [int(r["Dispatch_Id"]) for r in rows if "tta_argmax" in r["Kernel_Name"]]
-    lo, hi = (marks[-2], marks[-1]) if len(marks) >= 2 else (-1, 1 << 62)
-    step = [r for r in rows if lo < int(r["Dispatch_Id"]) <= hi]
+    step = kinds.steady_step(rows, key=lambda r: int(r["Dispatch_Id"]))
+    pairs, problems = kinds.match(step, LABELS)
+    for p in problems:
+        sys.stderr.write("pmc_summary: %s -- skipped\n" % p)
     out = collections.defaultdict(list)
-    for frag, prefix in KIND:
-        want = [l for l in LABELS if l.startswith(prefix)]
-        frags = frag if isinstance(frag, tuple) else (frag,)
-        have = [r for r in step if any(f in r["Kernel_Name"] for f in frags)]
-        if len(want) != len(have):
-            sys.stderr.write("pmc_summary: %d dispatches of %s vs %d labels -- skipped\n" % (len(have), frag, len(want)))
-            continue
-        for l, r in zip(want, have):
-            out[l].append(float(r["Counter_Value"]) * 1024.0)
+    for label, disp in pairs:
+        if label is not None:
+            out[label].append(sum(float(r["Counter_Value"]) for r in disp) * 1024.0)
     return {k: sum(v) / len(v) for k, v in out.items()}
 
 

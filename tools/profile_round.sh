@@ -12,7 +12,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-f
 echo "trace done"
 # the same with the two pipeline streams folded into one: per-kernel durations without the other stream's kernels on the CUs
 # (whether the tracer serialises the two streams by itself differs from box to box)
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-raw --no-pipeline > $OUT/bench_trace_serial.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-raw --no-pipeline --label-log $OUT/labels_serial.json > $OUT/bench_trace_serial.log 2>&1
 echo "serial trace done"
 PMCARGS="--steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-raw --no-pipeline"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 -u $R/bench.py $PMCARGS --label-log $OUT/labels.json > $OUT/bench_fetch.log 2>&1
@@ -31,6 +31,9 @@ python3 $R/profiles/step_breakdown.py $T > $OUT/step_breakdown.txt 2>&1 || true
 S2=$(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1); T2=$(find $OUT/trace_serial -name "*kernel_trace.csv" | head -1)
 cp $S2 $OUT/kernel_stats_serial.csv
 python3 $R/profiles/step_breakdown.py $T2 > $OUT/step_breakdown_serial.txt 2>&1 || true
+# per-LABEL durations of the serial trace (launch order = dispatch order), with the roofline fraction of every labelled launch
+grep "^{" $OUT/bench_trace_serial.log | tail -1 > $OUT/bench_traced_serial.json.log || true
+python3 $R/profiles/label_durations.py $T2 $OUT/labels_serial.json $OUT/bench_traced_serial.json.log > $OUT/label_durations.csv 2> $OUT/label_durations.err || true
 grep "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench_traced.json.log || true
 rm -rf $OUT/trace $OUT/trace_serial $OUT/fetch $OUT/write $OUT/mfma
 ls -la $OUT
