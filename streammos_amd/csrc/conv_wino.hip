@@ -272,7 +272,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
 #define WINO_KSTEP(v, vn, nbuf, ni, HEAD, TAIL, NVM)                   \
   do {                                                                 \
     WINO_A_READ(afb, so0, 1);                                          \
-    WINO_W_LOAD(so2);                                                  \
     HEAD;                                                              \
     WINO_D_READ(vn, nbuf, ni);                                         \
     SMOS_FENCE();                                                      \
@@ -371,53 +370,84 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     }
   };
 
-  // ---- prologue: region of chunk 0 in buffer 0, slices 0 and 1 in slots 0 and 1, B operands of k-step 0 ----
+  // ---- prologue: region of chunk 0 in buffer 0, slices 0 and 1 in slots 0 and 1, B operands of k-step 0, first half of
+  //      chunk 1's region on its way ----
+  auto advance = [&](int& it_, int& c_) {
+    if (++c_ == a.nchunk) {
+      c_ = 0;
+      ++it_;
+    }
+  };
+  int it = 0, c = 0;                 // chunk g
+  int it1 = 0, c1 = 0;               // chunk g + 1
+  advance(it1, c1);
   WinoItem cur = item_of(0);
+  WinoItem nxt = c1 == 0 ? item_of(it1) : cur;
   int so0 = 0, so1 = kSlot, so2 = 2 * kSlot;
+  constexpr bool kEarly = MB == 1;   // region requests one k-step earlier (needs the registers mb = 2 does not have)
   WINO_STAGE_LOAD_A(cur, 0, true);
   WINO_W_LOAD(so0);
   WINO_W_LOAD(so1);
   WINO_STAGE_WRITE_A(lds);
   WINO_STAGE_LOAD_B(cur, 0, true);
   WINO_STAGE_WRITE_B(lds);
-  WINO_VM_WAIT(0);
+  if constexpr (kEarly) WINO_STAGE_LOAD_A(nxt, c1, 1 < total);
+  WINO_VM_WAIT(kEarly ? 3 : 0);      // everything but the three requests just issued
   ring_barrier();
   WINO_D_READ(va, lds, 0);
   WINO_T_ROWS(va);
   WINO_T_COLS(va);
   WINO_A_READ(afa, so0, 0);
 
-  int it = 0, c = 0;
   float* buf_cur = lds;
   float* buf_nxt = lds + kWInWords;
 #pragma unroll 1
   for (int g = 0; g < total; ++g) {
-    int c_n = c + 1, it_n = it;
-    if (c_n == a.nchunk) {
-      c_n = 0;
-      it_n = it + 1;
+    int it2 = it1, c2 = c1;          // chunk g + 2
+    advance(it2, c2);
+    const WinoItem nn = c2 == 0 ? item_of(it2) : nxt;              // past the last item: clamped, loads masked off
+    // Region of chunk g + 1, through ONE set of three registers: first half requested at the head of k-step 3 of chunk g - 1
+    // and stored at the tail of k-step 0, second half requested right behind that store and stored at the tail of k-step 2
+    // (about two k-steps of latency each); the barrier that ends k-step 2 publishes the buffer, so that k-step 3 can already
+    // read the first patch of chunk g + 1.  hipcc waits vmcnt(0) at the use of an ordinary load while an LDS-DMA is in
+    // flight, so in the k-steps with a region store the weight DMA is issued BEHIND the store, otherwise at the head.
+    // Last argument: the VMEM requests the wave issues in the k-step itself, i.e. what may still be in flight at its barrier.
+    if constexpr (kEarly) {
+      WINO_KSTEP(va, vb, buf_cur, 1, (void)0,
+                 WINO_STAGE_WRITE_A(buf_nxt); WINO_W_LOAD(so2); WINO_STAGE_LOAD_B(nxt, c1, g + 1 < total), MB + 3);
+      WINO_KSTEP(vb, va, buf_cur, 2, WINO_W_LOAD(so2), (void)0, MB + 3);
+      WINO_KSTEP(va, vb, buf_cur, 3, (void)0, WINO_STAGE_WRITE_B(buf_nxt); WINO_W_LOAD(so2), MB);
+      // (when an item ends with this chunk, the request goes out behind the epilogue instead of across it)
+      WINO_KSTEP(vb, va, buf_nxt, 0, WINO_W_LOAD(so2); if (c1 != 0) WINO_STAGE_LOAD_A(nn, c2, g + 2 < total), (void)0, MB + 3);
+      if (c1 == 0) {
+        epilogue(cur);
+        cur = nxt;
+        WINO_STAGE_LOAD_A(nn, c2, g + 2 < total);
+      }
+    } else {
+      // mb = 2 has no register to spare for the longer flight: first half requested at the head of k-step 0 and stored at the
+      // tail of k-step 1, second half requested behind that store and stored at the tail of k-step 2
+      WINO_KSTEP(va, vb, buf_cur, 1, WINO_W_LOAD(so2); WINO_STAGE_LOAD_A(nxt, c1, g + 1 < total), (void)0, MB + 3);
+      WINO_KSTEP(vb, va, buf_cur, 2, (void)0,
+                 WINO_STAGE_WRITE_A(buf_nxt); WINO_W_LOAD(so2); WINO_STAGE_LOAD_B(nxt, c1, g + 1 < total), MB + 3);
+      WINO_KSTEP(va, vb, buf_cur, 3, (void)0, WINO_STAGE_WRITE_B(buf_nxt); WINO_W_LOAD(so2), MB);
+      WINO_KSTEP(vb, va, buf_nxt, 0, WINO_W_LOAD(so2), (void)0, MB);
+      if (c1 == 0) {
+        epilogue(cur);
+        cur = nxt;
+      }
     }
-    const WinoItem nxt = c_n == 0 ? item_of(it_n) : cur;           // past the last item: clamped, loads masked off
-    const bool more = g + 1 < total;
-    // The next chunk's region: first half requested at the head of k-step 0 and stored at the tail of k-step 1, second half
-    // requested right behind that store and stored at the tail of k-step 2; the barrier that ends k-step 2 publishes the
-    // buffer, so that k-step 3 can already read the first patch of the next chunk.
-    // (last argument: the VMEM requests a wave issues in the k-step itself -- its own weight DMA and region requests -- i.e.
-    // what may still be in flight at the k-step's barrier)
-    WINO_KSTEP(va, vb, buf_cur, 1, WINO_STAGE_LOAD_A(nxt, c_n, more), (void)0, MB + 3);
-    WINO_KSTEP(vb, va, buf_cur, 2, (void)0, WINO_STAGE_WRITE_A(buf_nxt); WINO_STAGE_LOAD_B(nxt, c_n, more), MB + 3);
-    WINO_KSTEP(va, vb, buf_cur, 3, (void)0, WINO_STAGE_WRITE_B(buf_nxt), MB);
-    WINO_KSTEP(vb, va, buf_nxt, 0, (void)0, (void)0, MB);
-    if (c_n == 0) {
-      epilogue(cur);
-      cur = nxt;
-    }
-    it = it_n;
-    c = c_n;
+    nxt = nn;
+    it = it1;
+    c = c1;
+    it1 = it2;
+    c1 = c2;
     float* sw = buf_cur;
     buf_cur = buf_nxt;
     buf_nxt = sw;
   }
+  (void)it;
+  (void)c;
 }
 
 }  // namespace smos
