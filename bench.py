@@ -128,6 +128,17 @@ def algorithmic_flops(label, ctx=None):
     return 0
 
 
+def executed_launch_flops(label, wino=True):
+    """FLOPs one labelled launch issues on the matrix cores: the algorithmic count, except that a stride-1 3x3 convolution
+    in the Winograd F(2x2, 3x3) form issues 4 instead of 9 multiply-adds per output and channel pair."""
+    fl = algorithmic_flops(label)
+    if fl and wino and label.startswith("conv_cl["):
+        geo = _conv_geometry(label.split("[", 1)[1].rstrip("]"))
+        if (geo["kh"], geo["kw"]) == (3, 3) and geo["ho"] == geo["h"] and geo["wo"] == geo["w"] and geo["cin"] % 16 == 0 and geo["cout"] % 16 == 0:
+            return fl * 4 // 9
+    return fl
+
+
 def executed_flops(engine, b, n, t, stem_class_rows):
     """FLOPs the engine really executes on the matrix cores for one scan (batch of b TTA samples, n padded points, t stacked
     scans): walks the engine's own folded weights.  Differs from the reference's dense count (0.53 TFLOP) by the
@@ -251,6 +262,90 @@ def cpu_baseline(frames, state_dict, n_timed):
                       "(forward + TTA argmax, voting excluded)" % (1, n_timed, FRAME_POINT_NUM)}
 
 
+def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4):
+    """BASELINE configs[4] on ONE GPU (reported beside `value`, never as it): the stage-2 training step of
+    train_StreamMOS_seg.py:58,165-190 -- StreamMOS_seg.AttNet, everything but `refine.*` frozen, SyncBatchNorm conversion +
+    DistributedDataParallel(find_unused_parameters=True) on the 'nccl' (= RCCL) backend with a process group of one rank,
+    model.train(), three chained forwards per step (models/StreamMOS_seg.py:173-196), backward, SGD step -- at the
+    reference's training shape (batch_size_per_gpu 4, Train.frame_point_num 130000, config/StreamMOS_seg.py:5,27) on
+    synthetic scans and seeded targets.  Counts the collectives a step issues (a SyncBatchNorm layer in train mode
+    all_gathers its (mean, invstd, count) in every forward whether or not its weights are frozen)."""
+    import collections
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from streammos_amd import preprocess, synth
+    from streammos_amd.refapi.config import StreamMOS_seg as cfg
+    from streammos_amd.refapi.models import StreamMOS_seg
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    counts = collections.Counter()
+    patched = []
+    for name in ("all_reduce", "all_gather", "all_gather_into_tensor", "reduce", "broadcast", "reduce_scatter_tensor"):
+        orig = getattr(dist, name, None)
+        if orig is None:
+            continue
+
+        def wrap(*a, _orig=orig, _name=name, **kw):
+            counts[_name] += 1
+            return _orig(*a, **kw)
+        setattr(dist, name, wrap)
+        patched.append((name, orig))
+    try:
+        net = StreamMOS_seg.AttNet(cfg.get_config()[2])
+        net.load_state_dict(synth.seeded_state_dict(net.state_dict()), strict=True)
+        trainable = StreamMOS_seg.freeze_for_stage2(net)
+        n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in net.modules())
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net).to(device)
+        model = DistributedDataParallel(net, device_ids=[device.index], output_device=device.index, find_unused_parameters=True)
+        opt = torch.optim.SGD(trainable, lr=0.02, momentum=0.9, nesterov=True, weight_decay=1e-3)
+        spec = preprocess.VoxelSpec()
+        scans = [synth.synthetic_scan(7000 + k) for k in range(5)]
+        poses = [synth.synthetic_pose(k) for k in range(5)]
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        data = {}
+        for i in range(3):                                     # three consecutive samples, chained through the memory
+            idx = preprocess.window_indices(i, 5, 3)
+            smp = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
+            for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"):
+                data["%s_%d" % (k, i)] = torch.from_numpy(np.ascontiguousarray(smp[k][:batch])).to(device)
+            data["pcds_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
+            data["pcds_bev_target_%d" % i] = torch.randint(0, 3, (batch, 256, 256, 1), generator=gen).to(device)
+            data["pcds_bf_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
+        model.train()
+
+        def step():
+            loss = model(data)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        counts.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(batch * steps / dt, 3), "unit": "samples/s (one GPU; a sample = 3 chained forwards + backward)",
+                "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "batch_per_gpu": batch, "frame_point_num": frame_point_num,
+                "loss": round(float(loss), 5), "batchnorm_layers": n_bn, "trainable_tensors": len(trainable),
+                "collectives_per_step": {k: v // steps for k, v in sorted(counts.items())},
+                "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                "note": "BASELINE configs[4] on one GPU: stage-2 step (all but refine.* frozen) under SyncBatchNorm + DDP on a "
+                        "one-rank RCCL group, module graph with torch autograd (MIOpen convs; VoxelMaxPool / deformable-attention "
+                        "forward and backward on the HIP kernels); reported beside `value`, never as it"}
+    finally:
+        for name, orig in patched:
+            setattr(dist, name, orig)
+        if own_group:
+            dist.destroy_process_group()
+
+
 def dry_launch(args):
     """The launch path without the GPU: every rank joins a gloo group, the barrier-bracketed "timed region" is K
     barriers, the MAX over ranks is taken as in the real run and rank 0 prints the line with the group's real size."""
@@ -294,6 +389,8 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=4, help="timed scans of the CPU baseline (0 = skip); 4 scans = about 15 s")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
+    ap.add_argument("--train-steps", type=int, default=3,
+                    help="timed stage-2 training steps on one GPU (BASELINE configs[4]; 0 = skip); reported beside value")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only rehearse the rank launch: gloo ranks join the group, time a barrier, rank 0 prints n_gpus")
     ap.add_argument("--label-log", default=None,
@@ -419,10 +516,43 @@ def main():
                              "frac": round(achieved / HBM_PEAK_GBS, 4)}, **common)
             if ctx.get("stem_rows") is not None:
                 roof["stem_rows_per_launch"] = round(ctx["stem_rows"])
+        if roof:
+            # The same launch inside a SERIAL step (one stream, the two pipeline stages one after the other): in the timed
+            # region it shares the CUs with the other stage's kernels, which stretches its HIP-event time by about 2x --
+            # a property of the pipelining, not of the kernel.  The serial step is also what `rocprofv3 --kernel-trace` of
+            # `bench.py --no-pipeline` measures, so `frac` can be checked against profiles/rNN_label_durations.csv
+            # (tools/profile_round.sh), row by row.  in_step_* keeps the figure from the timed (pipelined) region.
+            serial = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=False)
+            for i in range(2):
+                serial.step(*dev_frames[i % len(dev_frames)])
+            torch.cuda.synchronize()
+            with profiling.kernel_timer(only=dominant) as kt_ser:
+                for i in range(8):
+                    serial.step(*dev_frames[(2 + i) % len(dev_frames)])
+            ser = kt_ser.summary().get(dominant)
+            if ser is not None:
+                iso = ser[2]
+                roof["in_step_launch_ms"] = roof["avg_launch_ms"]
+                roof["in_step_frac"] = roof["frac"]
+                roof["serial_step_launch_ms"] = round(iso, 4)
+                if roof["bound"] == "mfma":
+                    ach = roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12
+                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / FP32_PEAK_TFLOPS, 4)
+                else:
+                    ach = roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9
+                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / HBM_PEAK_GBS, 4)
+                roof["avg_launch_ms"] = round(iso, 4)
+                roof["launches"] = ser[0]
+                roof["clock"] = ("HIP events (torch.cuda.Event) on the launch stream around every launch of the dominant label in 8 "
+                                 "serial steps (StreamRunner(pipeline=False): one stream) right after the timed region = what "
+                                 "rocprofv3 --kernel-trace of `bench.py --no-pipeline` reports per launch "
+                                 "(profiles/rNN_label_durations.csv); in_step_* = the same launch inside the timed two-stream "
+                                 "region, where it shares the CUs with the other stage's kernels")
+            serial.close()
+            del serial
         if roof and dominant.startswith("conv_cl"):
-            # the same launch (same operands) alone on the GPU: in the timed region it shares the chip with the other
-            # pipeline stage's kernels, which stretches its HIP-event time; rocprofv3 --kernel-trace serialises the two
-            # streams, so ITS per-kernel mean (profiles/r02*_kernel_stats.csv) corresponds to this isolated figure
+            # and re-run 30 times back to back with its own operands (inputs and weights hot in L2 / Infinity Cache): an upper
+            # bound of what the kernel does, reported beside `frac`, never as it
             profiling.request_replay(dominant)
             one_step(0)
             one_step(1)
@@ -432,21 +562,10 @@ def main():
                 with profiling.kernel_timer(only=dominant) as kt_iso:
                     for _ in range(30):
                         again()
-                iso = kt_iso.summary()[dominant][2]
-                roof["in_step_launch_ms"] = roof["avg_launch_ms"]
-                roof["in_step_frac"] = roof["frac"]
-                roof["isolated_launch_ms"] = round(iso, 4)
-                if roof["bound"] == "mfma":
-                    ach = roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12
-                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / FP32_PEAK_TFLOPS, 4)
-                else:
-                    ach = roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9
-                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / HBM_PEAK_GBS, 4)
-                roof["avg_launch_ms"] = round(iso, 4)
-                roof["clock"] = ("HIP events (torch.cuda.Event) on the launch stream around 30 re-runs of the dominant launch with "
-                                 "its own operands, alone on the GPU, right after the timed region (= what rocprofv3 "
-                                 "--kernel-trace reports: the tracer serialises the two pipeline streams); in_step_* = the same "
-                                 "launch inside the timed region, where it shares the CUs with the other stream's kernels")
+                hot = kt_iso.summary()[dominant][2]
+                roof["hot_replay_launch_ms"] = round(hot, 4)
+                roof["hot_replay_frac"] = round((roof["algorithmic_flops_per_launch"] / FP32_PEAK_TFLOPS / 1e12 if roof["bound"] == "mfma"
+                                                 else roof["algorithmic_bytes_per_launch"] / HBM_PEAK_GBS / 1e9) / (hot * 1e-3), 4)
         if roof and dominant.startswith("point_head") and eng is not None:
             # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
             from streammos_amd import ops as _ops
@@ -561,6 +680,13 @@ def main():
                                        "ms_per_batched_step": round(1e3 * dt / n_it, 3),
                                        "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
                                        "note": "BASELINE configs[2]; reported beside `value`, never as `value`"}
+        if world == 1 and args.train_steps > 0:
+            runner = dev_frames = None            # the inference buffers are not needed any more
+            torch.cuda.empty_cache()
+            try:
+                line["stage2_training"] = train_bench(device, args.train_steps)
+            except Exception as e:          # never lose the headline line to the side measurement
+                line["stage2_training"] = {"error": repr(e)[:300]}
         if world == 1 and args.cpu_scans > 0:
             line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
         print(json.dumps(line), flush=True)

@@ -20,6 +20,8 @@
 //      "rows"  : one lane per channel, a group of lanes per point -> point-major features and a
 //                channels-last grid: every wave instruction is one or two contiguous 128/256-byte rows,
 //                the shape HBM-side atomics run at full rate on MI355X.
+#include <hip/hip_fp16.h>
+
 #include "smos_common.h"
 
 namespace smos {
@@ -181,6 +183,107 @@ __global__ __launch_bounds__(kBlock) void vmp_bwd_points(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// float16 / float64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, point_deep_cuda_kernel.cu:147,168; the
+// model itself only ever calls float32, models/StreamMOS.py:18).  Correctness path, not tuned: the reference's own
+// algorithm -- a racing member store per occupied cell (kPass 0, VoxelMaxPoolUpdateOutputInit :60-79), then an atomic max over
+// all members (kPass 1, :82-99).  float64: the signed-max / unsigned-min pair on the 64-bit pattern (no CAS loop); float16:
+// compare-and-swap on the containing 32-bit word, as atomics.cuh:225-242 does.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct VmpNum;
+template <>
+struct VmpNum<double> {
+  static __device__ __forceinline__ float to_float(double v) { return (float)v; }
+  static __device__ __forceinline__ bool is_nan(double v) { return v != v; }
+  static __device__ __forceinline__ void atom_max(double* p, double v) {
+    if (v >= 0.0)
+      atomicMax(reinterpret_cast<long long*>(p), __double_as_longlong(v));
+    else
+      atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+  }
+  static __device__ __forceinline__ bool equal(double a, double b) { return a == b; }
+};
+template <>
+struct VmpNum<__half> {
+  static __device__ __forceinline__ float to_float(__half v) { return __half2float(v); }
+  static __device__ __forceinline__ bool is_nan(__half v) { return __hisnan(v); }
+  static __device__ __forceinline__ void atom_max(__half* p, __half v) {
+    unsigned int* word = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p) - (reinterpret_cast<size_t>(p) & 2));
+    const bool hi = (reinterpret_cast<size_t>(p) & 2) != 0;
+    const unsigned short vb = __half_as_ushort(v);
+    unsigned int old = *word, assumed;
+    do {
+      assumed = old;
+      const unsigned short cur = hi ? (unsigned short)(old >> 16) : (unsigned short)(old & 0xffffu);
+      if (!(__half2float(v) > __half2float(__ushort_as_half(cur)))) return;        // the cell already holds a value >= v
+      const unsigned int want = hi ? ((old & 0xffffu) | ((unsigned int)vb << 16)) : ((old & 0xffff0000u) | vb);
+      old = atomicCAS(word, assumed, want);
+    } while (assumed != old);
+  }
+  static __device__ __forceinline__ bool equal(__half a, __half b) { return __half2float(a) == __half2float(b); }
+};
+
+template <typename T>
+__device__ __forceinline__ int64_t cell_offset_t(const T* __restrict__ ind_row, const VmpGeom& g) {
+  float row[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+    if (d < g.D) row[d] = VmpNum<T>::to_float(ind_row[d]);      // static_cast<float>(pcds_ind), cuda_kernel.cu:40
+  return cell_offset(row, g);
+}
+
+template <typename T, int kPass>
+__global__ __launch_bounds__(kBlock) void vmp_fwd_generic(const T* __restrict__ feat, const T* __restrict__ ind, T* __restrict__ out,
+                                                          int64_t* __restrict__ vidx, VmpGeom g, int64_t BS, int64_t C, int64_t N) {
+  const int64_t total = BS * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / N;
+    const int64_t n = i - b * N;
+    int64_t off = cell_offset_t<T>(ind + i * g.D, g);
+    if (off < 0) continue;
+    off += b * g.out_b;
+    if (kPass == 0 && vidx) vidx[i] = off;
+    const T* __restrict__ f = feat + b * g.fs_b + n * g.fs_n;
+    for (int64_t c = 0; c < C; ++c) {
+      const T v = f[c * g.fs_c];
+      T* p = out + off + c * g.out_c;
+      if (kPass == 0)
+        *p = v;
+      else if (!VmpNum<T>::is_nan(v))
+        VmpNum<T>::atom_max(p, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void vmp_bwd_generic(const T* __restrict__ feat, const T* __restrict__ ind, const T* __restrict__ out,
+                                                          const T* __restrict__ grad_out, T* __restrict__ grad_feat, VmpGeom g,
+                                                          int64_t BS, int64_t C, int64_t N) {
+  const int64_t total = BS * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / N;
+    const int64_t n = i - b * N;
+    int64_t off = cell_offset_t<T>(ind + i * g.D, g);
+    if (off < 0) continue;
+    off += b * g.out_b;
+    const int64_t fo = b * g.fs_b + n * g.fs_n;
+    for (int64_t c = 0; c < C; ++c) {
+      const int64_t o = off + c * g.out_c;
+      if (VmpNum<T>::equal(out[o], feat[fo + c * g.fs_c])) grad_feat[fo + c * g.fs_c] = grad_out[o];
+    }
+  }
+}
+
+template <typename T>
+static int vmp_fwd_generic_launch(const void* feat, const void* ind, void* out, int64_t* vidx, const VmpGeom& g, int64_t BS,
+                                  int64_t C, int64_t N, hipStream_t s) {
+  dim3 grid(grid_for(BS * N));
+  hipLaunchKernelGGL((vmp_fwd_generic<T, 0>), grid, dim3(kBlock), 0, s, (const T*)feat, (const T*)ind, (T*)out, vidx, g, BS, C, N);
+  hipLaunchKernelGGL((vmp_fwd_generic<T, 1>), grid, dim3(kBlock), 0, s, (const T*)feat, (const T*)ind, (T*)out, vidx, g, BS, C, N);
+  return check_launch("voxel_maxpool_fwd");
+}
+
 static int fill_geom(VmpGeom& g, const int64_t* feat_stride, const int64_t* out_stride, int32_t D,
                      const int64_t* out_size, const float* scale) {
   SMOS_REQUIRE(D >= 1 && D <= 4, "voxel_maxpool: D=%d outside 1..4", (int)D);
@@ -208,9 +311,8 @@ extern "C" int smos_voxel_maxpool_fwd(const void* feat, const int64_t* feat_stri
                                       const int64_t* out_stride, int64_t* voxel_max_idx, int64_t BS, int64_t C,
                                       int64_t N, int32_t D, const int64_t* out_size, const float* scale,
                                       int32_t dtype, int32_t* flag_ws, smos_stream_t stream) {
-  if (dtype != SMOS_F32) {
-    set_error("voxel_maxpool_fwd: only float32 is implemented (dtype code %d); the model path casts to "
-              "float32 before the op (models/StreamMOS.py:18)", (int)dtype);
+  if (dtype != SMOS_F32 && dtype != SMOS_F16 && dtype != SMOS_F64) {
+    set_error("voxel_maxpool_fwd: unknown dtype code %d", (int)dtype);
     return SMOS_ERR_UNSUPPORTED;
   }
   SMOS_REQUIRE(BS >= 0 && C >= 0 && N >= 0, "voxel_maxpool_fwd: negative size");
@@ -219,6 +321,8 @@ extern "C" int smos_voxel_maxpool_fwd(const void* feat, const int64_t* feat_stri
   VmpGeom g;
   if (int rc = fill_geom(g, feat_stride, out_stride, D, out_size, scale)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == SMOS_F64) return vmp_fwd_generic_launch<double>(feat, ind, out, voxel_max_idx, g, BS, C, N, s);
+  if (dtype == SMOS_F16) return vmp_fwd_generic_launch<__half>(feat, ind, out, voxel_max_idx, g, BS, C, N, s);
   const float* f = (const float*)feat;
   const float* in = (const float*)ind;
   float* o = (float*)out;
@@ -270,8 +374,8 @@ extern "C" int smos_voxel_maxpool_bwd(const void* feat, const int64_t* feat_stri
                                       const void* grad_out, const int64_t* out_stride, void* grad_feat, int64_t BS,
                                       int64_t C, int64_t N, int32_t D, const int64_t* out_size, const float* scale,
                                       int32_t dtype, smos_stream_t stream) {
-  if (dtype != SMOS_F32) {
-    set_error("voxel_maxpool_bwd: only float32 is implemented (dtype code %d)", (int)dtype);
+  if (dtype != SMOS_F32 && dtype != SMOS_F16 && dtype != SMOS_F64) {
+    set_error("voxel_maxpool_bwd: unknown dtype code %d", (int)dtype);
     return SMOS_ERR_UNSUPPORTED;
   }
   SMOS_REQUIRE(BS >= 0 && C >= 0 && N >= 0, "voxel_maxpool_bwd: negative size");
@@ -279,6 +383,16 @@ extern "C" int smos_voxel_maxpool_bwd(const void* feat, const int64_t* feat_stri
   SMOS_REQUIRE(feat && ind && out && grad_out && grad_feat, "voxel_maxpool_bwd: null device pointer");
   VmpGeom g;
   if (int rc = fill_geom(g, feat_stride, out_stride, D, out_size, scale)) return rc;
+  if (dtype == SMOS_F64) {
+    hipLaunchKernelGGL((vmp_bwd_generic<double>), dim3(grid_for(BS * N)), dim3(kBlock), 0, (hipStream_t)stream, (const double*)feat,
+                       (const double*)ind, (const double*)out, (const double*)grad_out, (double*)grad_feat, g, BS, C, N);
+    return check_launch("voxel_maxpool_bwd");
+  }
+  if (dtype == SMOS_F16) {
+    hipLaunchKernelGGL((vmp_bwd_generic<__half>), dim3(grid_for(BS * N)), dim3(kBlock), 0, (hipStream_t)stream, (const __half*)feat,
+                       (const __half*)ind, (const __half*)out, (const __half*)grad_out, (__half*)grad_feat, g, BS, C, N);
+    return check_launch("voxel_maxpool_bwd");
+  }
   hipLaunchKernelGGL(vmp_bwd_points, dim3(grid_for(BS * N)), dim3(kBlock), 0, (hipStream_t)stream, (const float*)feat,
                      (const float*)ind, (const float*)out, (const float*)grad_out, (float*)grad_feat, g, BS, C, N);
   return check_launch("voxel_maxpool_bwd");

@@ -344,8 +344,11 @@ class InferenceEngine:
                 return self._encode_cl(point_feat, pcds_coord, pcds_sphere_coord)
             return self._encode(point_feat, pcds_coord, pcds_sphere_coord)
 
-    def decode(self, enc, memory=None):
-        return self.decode_heads(enc, self.decode_memory(enc, memory))
+    def decode(self, enc, memory=None, want_aux=True):
+        """want_aux=False: the three BEV aux maps (training-time supervision heads, models/StreamMOS.py:106-111) are not
+        computed and come back as None -- the streaming runner throws them away (val_StreamMOS.py:97 uses pred_cls only);
+        AttNet.infer always returns them."""
+        return self.decode_heads(enc, self.decode_memory(enc, memory), want_aux)
 
     def decode_memory(self, enc, memory=None):
         """The only part that is serial across frames: third BEV stage + deformable-attention fusion with the previous
@@ -356,11 +359,11 @@ class InferenceEngine:
                 return self._temporal_fusion(x2, memory, channels_last=True)
             return self._temporal_fusion(enc["x2"], memory)
 
-    def decode_heads(self, enc, x2):
+    def decode_heads(self, enc, x2, want_aux=True):
         """Decoder convs, aux heads, bev->point gather and the point heads; nothing here feeds the next frame."""
         with torch.no_grad(), self._conv_flags():
             if self.layout == "cl":
-                return self._decode_cl(enc, x2)
+                return self._decode_cl(enc, x2, want_aux)
             return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
@@ -490,7 +493,7 @@ class InferenceEngine:
         # res2 on the encode side 158.6 vs 167.5 scans/s)
         return {"x0cat": x0cat, "x1cat": x1cat, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
 
-    def _decode_cl(self, enc, x2):
+    def _decode_cl(self, enc, x2, want_aux=True):
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
         k = self.aux[2]
         if self.upconv:
@@ -504,14 +507,16 @@ class InferenceEngine:
                 rows = src.permute(0, 2, 3, 1).reshape(bb * hh * ww, cc)
                 return torch.addmm(wb[1], rows, wb[0].reshape(wb[0].shape[0], -1).t()).view(bb, hh, ww, -1).permute(0, 3, 1, 2)
 
-            aux = [head1x1(x0cat, self.aux_split[0])]
-            for src, wb in ((x1cat, self.aux_split[1]), (x2, self.aux_split[2])):
-                # a 1x1 convolution commutes with the (linear, weights summing to 1) bilinear resize
-                aux.append(F.interpolate(head1x1(src, wb), size=size, mode="bilinear", align_corners=True))
+            aux = (None, None, None)
+            if want_aux:
+                aux = [head1x1(x0cat, self.aux_split[0])]
+                for src, wb in ((x1cat, self.aux_split[1]), (x2, self.aux_split[2])):
+                    # a 1x1 convolution commutes with the (linear, weights summing to 1) bilinear resize
+                    aux.append(F.interpolate(head1x1(src, wb), size=size, mode="bilinear", align_corners=True))
         else:
             dec_in = ops.upsample_concat_cl([x0cat, x1cat, x2], tuple(x0cat.shape[2:]))
             y = self._conv(dec_in, self.conv_1[0], self.conv_1[1], LEAKY)
-            aux = F.conv2d(dec_in, self.aux[0], self.aux[1])
+            aux = F.conv2d(dec_in, self.aux[0], self.aux[1]) if want_aux else (None, None, None)
         bev_feat = self._conv(y, self.conv_2[0], self.conv_2[1], LEAKY)
         ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
         return self._point_heads(fuse, aux, k, x2)

@@ -466,7 +466,7 @@ class StreamRunner:
                     t.record_stream(main)
                     t.record_stream(self._side)
             self._pre_enc = (next_dev, nxt)
-        return eng.decode(enc, self.memory if self.frame > 0 else None)
+        return eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False)    # the runner uses pred_cls only
 
     @torch.no_grad()
     def step(self, dev, pose=None, next_dev=None):

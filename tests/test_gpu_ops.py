@@ -91,9 +91,36 @@ def test_voxel_maxpool_full_size_properties():
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
+@pytest.mark.parametrize("name", sorted(cases.voxel_maxpool_cases()))
+def test_voxel_maxpool_half_and_double(name, dtype):
+    """The reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF (point_deep_cuda_kernel.cu:147,168): float16 and float64
+    through the same entry points, forward and backward, bit for bit against the numpy restatement run on the SAME rounded
+    inputs (a max picks one of its inputs: exact in any dtype) and, for float64, against the CPU twin."""
+    feat, ind, out_size, scale = cases.voxel_maxpool_cases()[name]
+    npdt = np.float64 if dtype == torch.float64 else np.float16
+    feat_t, ind_t = feat.astype(npdt), ind.astype(npdt)
+    want, want_idx = ops_np.voxel_maxpool_fwd(feat_t, ind_t.astype(np.float32), out_size, scale)
+    f = torch.from_numpy(feat_t).to(DEV).unsqueeze(-1).requires_grad_(True)
+    i = torch.from_numpy(ind_t).to(DEV).unsqueeze(-1)
+    y = deep_point.VoxelMaxPool(f, i, out_size, scale)
+    assert y.dtype == dtype and np.array_equal(y.detach().cpu().numpy(), want.reshape(y.shape))
+    go = cases.grad_like(y.shape, name).astype(npdt)
+    y.backward(torch.from_numpy(go).to(DEV))
+    want_grad = ops_np.voxel_maxpool_bwd(feat_t, ind_t.astype(np.float32), want, go, out_size, scale)
+    assert np.array_equal(f.grad[..., 0].cpu().numpy(), want_grad)
+    idx = torch.full(ind.shape[:2], -1, dtype=torch.int64, device=DEV)
+    out = torch.zeros(y.shape, dtype=dtype, device=DEV)
+    ops.voxel_maxpool_fwd(f.detach()[..., 0], i[..., 0], out, out_size, scale, voxel_max_idx=idx)
+    assert torch.equal(out, y.detach()) and np.array_equal(idx.cpu().numpy(), want_idx)
+    if dtype == torch.float64:                       # and the DataLoader-side CPU twin (point_deep.cpu_kernel)
+        yc = deep_point.VoxelMaxPool(torch.from_numpy(feat_t).unsqueeze(-1), torch.from_numpy(ind_t).unsqueeze(-1), out_size, scale)
+        assert np.array_equal(yc.numpy(), y.detach().cpu().numpy())
+
+
 def test_voxel_maxpool_errors_are_loud():
-    f = torch.zeros((1, 2, 4, 1), device=DEV, dtype=torch.float16)
-    i = torch.zeros((1, 4, 2, 1), device=DEV, dtype=torch.float16)
+    f = torch.zeros((1, 2, 4, 1), device=DEV, dtype=torch.bfloat16)          # not a dtype the reference dispatches
+    i = torch.zeros((1, 4, 2, 1), device=DEV, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         deep_point.VoxelMaxPool(f, i, (4, 4), (1.0, 1.0))
     with pytest.raises(RuntimeError):

@@ -24,7 +24,7 @@ echo "mfma done"
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
 python3 $R/profiles/pmc_summary.py $F $W $OUT/labels.json > $OUT/pmc_traffic.json
 M=$(find $OUT/mfma -name "*counter_collection.csv" | head -1)
-python3 $R/profiles/mfma_busy_summary.py $M > $OUT/mfma_busy.txt
+python3 $R/profiles/mfma_busy_summary.py $M $OUT/labels.json > $OUT/mfma_busy.txt
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 cp $S $OUT/kernel_stats.csv
 python3 $R/profiles/step_breakdown.py $T > $OUT/step_breakdown.txt 2>&1 || true
