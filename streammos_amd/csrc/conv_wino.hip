@@ -100,9 +100,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   if (iters <= 0) return;
   const int total = iters * a.nchunk;
 
-  auto item_of = [&](int it) {
+  // the block's items in order: cout tile fastest, then the 32-column block, the 8-row block, the sample.  Only the first one is
+  // located with divisions; the walk is incremental (scalar selects; past the block's last item the coordinates are unused:
+  // every request for such a chunk is masked off)
+  auto first_item = [&]() {
     WinoItem t;
-    int u = first + (it < iters ? it : iters - 1);
+    int u = first;
     t.ct = u % a.nct;
     u /= a.nct;
     t.x0 = (u % a.xb) * 32;
@@ -110,6 +113,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
     t.y0 = (u % a.yb) * 8;
     t.b = u / a.yb;
     return t;
+  };
+  auto next_item = [&](const WinoItem& t) {
+    WinoItem n = t;
+    const bool w_ct = t.ct + 1 == a.nct;
+    const bool w_x = w_ct & (t.x0 + 32 >= a.xb * 32);
+    const bool w_y = w_x & (t.y0 + 8 >= a.yb * 8);
+    n.ct = w_ct ? 0 : t.ct + 1;
+    n.x0 = w_x ? 0 : t.x0 + (w_ct ? 32 : 0);
+    n.y0 = w_y ? 0 : t.y0 + (w_x ? 8 : 0);
+    n.b = t.b + (w_y ? 1 : 0);
+    return n;
   };
 
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -381,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   int it = 0, c = 0;                 // chunk g
   int it1 = 0, c1 = 0;               // chunk g + 1
   advance(it1, c1);
-  WinoItem cur = item_of(0);
-  WinoItem nxt = c1 == 0 ? item_of(it1) : cur;
+  WinoItem cur = first_item();
+  WinoItem nxt = c1 == 0 ? next_item(cur) : cur;
   int so0 = 0, so1 = kSlot, so2 = 2 * kSlot;
   constexpr bool kEarly = MB == 1;   // region requests one k-step earlier (needs the registers mb = 2 does not have)
   WINO_STAGE_LOAD_A(cur, 0, true);
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   for (int g = 0; g < total; ++g) {
     int it2 = it1, c2 = c1;          // chunk g + 2
     advance(it2, c2);
-    const WinoItem nn = c2 == 0 ? item_of(it2) : nxt;              // past the last item: clamped, loads masked off
+    const WinoItem nn = c2 == 0 ? next_item(nxt) : nxt;            // past the last item: unused, loads masked off
     // Region of chunk g + 1, through ONE set of three registers: first half requested at the head of k-step 3 of chunk g - 1
     // and stored at the tail of k-step 0, second half requested right behind that store and stored at the tail of k-step 2
     // (about two k-steps of latency each); the barrier that ends k-step 2 publishes the buffer, so that k-step 3 can already
