@@ -1,6 +1,7 @@
 // Shared by csrc/conv_igemm.hip and csrc/conv_rows.hip: argument block, ring barrier, scheduling fence, half-wave sum.
 #pragma once
 #include "smos_common.h"
+#include "conv_diag.h"
 
 namespace smos {
 
@@ -23,9 +24,7 @@ struct ConvArgs {
   int hq, xt;          // ceil(Ho / 4), ceil(Wo / 32)
   int n_items;         // B * hq * xt * nct
   float slope;         // activation: max(v, 0) + slope * min(v, 0) -- 1 none, 0 ReLU, 0.01 LeakyReLU
-#ifdef SMOS_CONV_STAMPS
-  unsigned long long* stamps;
-#endif
+  SMOS_STAMPS_ARG
   int x_bytes;         // B * H * W * xp * 4 (< 2^31: lanes outside the image use offset 2^31)
   int r_bytes, o_bytes, cout;   // B * Ho * Wo * rp * 4, B * Ho * Wo * op * 4, Cout
 };
@@ -34,18 +33,9 @@ struct ConvArgs {
 // prefetch once per stage.  Only LDS traffic has to be ordered here: every wave drains its own LDS queue (ring stores
 // landed, fragment reads returned), then the barrier.  The "memory" clobbers keep the compiler from moving ring accesses
 // across it.
-// Diagnostic builds only (tools/ablate_conv.sh): -DSMOS_CONV_ABLATE=<bits> removes one ingredient of the stage at a time
-// (1 barrier, 2 activation requests, 4 weight ring traffic, 8 epilogue stores) to time what is left; results are wrong.
-#ifndef SMOS_CONV_ABLATE
-#define SMOS_CONV_ABLATE 0
-#endif
-#ifndef SMOS_CONV_SCHED
-#define SMOS_CONV_SCHED 1      // 1: eight half groups (shipped); 0: four groups, the cut the in-kernel stamps were written for
-#endif
-
 __device__ __forceinline__ void ring_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (!(SMOS_CONV_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+  if (SMOS_CONV_KEEPS(1)) __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 

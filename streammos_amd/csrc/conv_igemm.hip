@@ -35,22 +35,6 @@
 
 namespace smos {
 
-// Diagnostic build only (-DSMOS_CONV_STAMPS, tools/conv_stamps.py): cycles a wave spends in each segment of the stage,
-// summed over its stages and written to a buffer of their own.  The shipped library contains no stamp.
-#ifdef SMOS_CONV_STAMPS
-#define SMOS_STAMP(k)                                                                              \
-  do {                                                                                             \
-    unsigned long long t_;                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    stamp_sum[k] += t_ - stamp_last;                                                               \
-    stamp_last = t_;                                                                               \
-  } while (0)
-#else
-#define SMOS_STAMP(k)
-#endif
-
 template <int MT, bool RES, bool SUMS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 ring[];     // 4 slots x 256 * MT float4, then Cout bias floats
@@ -191,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-  auto mfma_group = [&](const float4 (&af)[4][MT], const float4& bv, int i4) {
+  [[maybe_unused]] auto mfma_group = [&](const float4 (&af)[4][MT], const float4& bv, int i4) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i4][mt].x, bv.x, acc[mt], 0, 0, 0);
 #pragma unroll
@@ -269,15 +253,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
         }
         u32x4 ov;
         ov.x = __float_as_uint(o[0]); ov.y = __float_as_uint(o[1]); ov.z = __float_as_uint(o[2]); ov.w = __float_as_uint(o[3]);
-        if (!(SMOS_CONV_ABLATE & 8) || ov.x == 0x7fc12345u)      // ablated: keeps the values alive, stores ~never
+        if (SMOS_CONV_KEEPS(8) || ov.x == 0x7fc12345u)      // (diagnostic builds can drop the stores: conv_diag.h)
           __builtin_amdgcn_raw_buffer_store_b128(ov, osrd, ooff + 4u * (mt * 32 + 8 * g), 0, 0);
       }
     }
   };
 
-#ifdef SMOS_CONV_STAMPS
-  unsigned long long stamp_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
-#endif
+  SMOS_STAMPS_DECLARE();
   float4 b0[4], b1[4], b2[4], b3[4], af[4][MT];
   float4 ae0, ae1, ae2, ae3, ao0, ao1, ao2, ao3;       // weight slices of even / odd stages on their way to the ring
   // ---- prologue: slice 0 in the ring, slices 1 and 2 in registers, activations of stages 0, 1 and 2 requested ----
@@ -359,57 +341,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
     if (RES && c_left == 1) request_residual();    \
     if (pb_left == 0) next_tile_b();               \
   } while (0)
-#else
-#define SMOS_STAGE(bc, bp, sc, sn, n0, n1, n2, n3) \
-  do {                                             \
-    SMOS_STAMP(8);                                 \
-    mfma_group(af, bc[0], 0);                      \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(0);                                 \
-    if (!(SMOS_CONV_ABLATE & 4)) {                 \
-      park(sn, n0, n1, n2, n3);                    \
-      load_a(n0, n1, n2, n3);                      \
-      read_a(af, sc, 2);                           \
-      read_a(af, sc, 3);                           \
-    }                                              \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(1);                                 \
-    mfma_group(af, bc[1], 1);                      \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(2);                                 \
-    if (!(SMOS_CONV_ABLATE & 2)) load_b(bp);       \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(3);                                 \
-    mfma_group(af, bc[2], 2);                      \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(4);                                 \
-    advance_b();                                   \
-    ring_barrier();                                \
-    if (!(SMOS_CONV_ABLATE & 4)) {                 \
-      read_a(af, sn, 0);                           \
-      read_a(af, sn, 1);                           \
-    }                                              \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(5);                                 \
-    mfma_group(af, bc[3], 3);                      \
-    SMOS_FENCE();                                  \
-    SMOS_STAMP(6);                                 \
-    if (--c_left == 0) {                           \
-      epilogue();                                  \
-      c_left = a.nstage;                           \
-      ++c_it;                                      \
-    }                                              \
-    if (RES && c_left == 1) request_residual();    \
-    if (pb_left == 0) next_tile_b();               \
-    SMOS_STAMP(7);                                 \
-  } while (0)
+#endif      // SMOS_CONV_SCHED == 0 (diagnostic builds): conv_diag.h
 
-#endif
-
-#ifdef SMOS_CONV_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
-  const unsigned long long clk0 = stamp_last, real0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  SMOS_STAMPS_BEGIN();
   // Four stages per trip (the register sets and ring slots rotate with period 4); the loop runs whole trips only and the
   // last 0..3 stages follow as straight-line code.  hipcc's wait-count pass honours every path of the control-flow graph:
   // with guarded stages inside the loop ("if (g + 1 < total) stage 2; if (g + 2 < total) stage 3; ...") there are paths on
@@ -432,14 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
       if (g + 2 < total) SMOS_STAGE(b2, b1, 2, 3, ao0, ao1, ao2, ao3);
     }
   }
-#ifdef SMOS_CONV_STAMPS
-  if (a.stamps && lane == 0) {
-    for (int k = 0; k < 9; ++k) a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + k] = stamp_sum[k];
-    // shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
-    a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + 9] = __builtin_amdgcn_s_memtime() - clk0;
-    a.stamps[((int64_t)blockIdx.x * 4 + wave) * 11 + 10] = __builtin_amdgcn_s_memrealtime() - real0;
-  }
-#endif
+  SMOS_STAMPS_END();
 }
 
 }  // namespace smos
@@ -507,12 +434,7 @@ extern "C" int smos_conv_cl(const float* x, int64_t x_pitch, const float* wprep,
   a.hq = (int)hq; a.xt = (int)xt; a.n_items = (int)(B * hq * xt * nct);
   a.slope = act == 0 ? 1.0f : act == 1 ? 0.0f : 0.01f;
   a.x_bytes = (int)(B * H * W * x_pitch * 4);
-#ifdef SMOS_CONV_STAMPS
-  {
-    const char* e = getenv("SMOS_CONV_STAMP_PTR");      // device buffer of 4 * 9 * grid uint64, set by the diagnostic script
-    a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
-  }
-#endif
+  SMOS_STAMPS_HOST(a);
   a.r_bytes = res ? (int)(B * Ho * Wo * res_pitch * 4) : 0;
   a.o_bytes = (int)(B * Ho * Wo * out_pitch * 4);
   a.cout = (int)Cout;

@@ -371,9 +371,7 @@ extern "C" int smos_conv_rows_cl(const float* x, int64_t x_pitch, const float* w
   a.hq = (int)hq; a.xt = (int)xt; a.n_items = (int)(B * hq * xt * nct);
   a.slope = act == 0 ? 1.0f : act == 1 ? 0.0f : 0.01f;
   a.x_bytes = (int)(B * H * W * x_pitch * 4);
-#ifdef SMOS_CONV_STAMPS
-  a.stamps = nullptr;
-#endif
+  SMOS_STAMPS_HOST_NONE(a);
   a.r_bytes = res ? (int)(B * H * W * res_pitch * 4) : 0;
   a.o_bytes = (int)(B * H * W * out_pitch * 4);
   a.cout = (int)Cout;
