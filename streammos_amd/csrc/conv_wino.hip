@@ -133,55 +133,83 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   const __amdgpu_buffer_rsrc_t bsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.cout * 4 : 0, 0x00020000);
 
-  // ---- staging of a chunk's input region: thread = (pixel tid / 4 + 64 k, channel group tid % 4), k = 0..5 ----
+  // ---- staging of a chunk's input region (10 rows x 34 pixels x 16 channels = 1360 float4, 5.3 per thread).  Thread =
+  // (slot = tid / 4, channel group c4 = tid % 4).  Rounds 0..4 cover columns 0..31 of two region rows each: row 2 k + (slot >> 5)
+  // -- wave-uniform: slot >> 5 == wave >> 1 -- and column slot & 31; round 5 covers columns 32, 33 of all ten rows with its
+  // first 20 slots.  The address of rounds 0..4 is then a per-thread term plus a SCALAR per (item, chunk, round), the row test
+  // is scalar and the column test is shared by the rounds: a few vector instructions per request instead of a dozen and no
+  // exec-masked branch.  The per-thread terms are recomputed from an opaque copy of the slot where they are used: kept across
+  // the loop they would cost the registers mb = 2 does not have. ----
   const int xp = (int)a.xp;
-  const int sp0 = tid >> 2, sc4 = tid & 3;
+  const int sc4 = tid & 3;
+  const int s_pyw = wave >> 1;
+  const int row2_bytes = 2 * a.W * xp * 4;
   u32x4 st0, st1, st2;
-#define WINO_STAGE_ONE(dst, k, t, c, valid)                                                                        \
+#define WINO_SLOT(name)     \
+  int name = tid >> 2;      \
+  asm volatile("" : "+v"(name))
+  // origin = byte offset of region pixel (0, 0), channel 16 c -- "negative" in the first row / column of the image: unsigned
+  // wrap-around, the sum with the per-thread term is exact modulo 2^32 for every pixel inside the image
+#define WINO_STAGE_ORIGIN(t, c) ((unsigned)(((((t).b * a.H + (t).y0 - 1) * a.W + (t).x0 - 1) * xp + 16 * (c)) * 4))
+#define WINO_STAGE_ROW(dst, k, t, org, valid, trel, okx)                                                           \
   do {                                                                                                             \
-    int p_ = sp0 + 64 * (k);                                                                                       \
-    asm volatile("" : "+v"(p_));      /* opaque: (py, px) are recomputed here, not kept in 12 registers across the loop */ \
-    const int py_ = (p_ * 241) >> 13, px_ = p_ - 34 * py_;          /* p / 34 for p < 384 */                       \
-    const int gy_ = (t).y0 - 1 + py_, gx_ = (t).x0 - 1 + px_;                                                      \
-    const bool ok_ = (valid) & (p_ < kWRegPix) & ((unsigned)gy_ < (unsigned)a.H) & ((unsigned)gx_ < (unsigned)a.W); \
-    const unsigned off_ = ok_ ? (unsigned)((((t).b * a.H + gy_) * a.W + gx_) * xp + 16 * (c) + 4 * sc4) * 4u : 0x80000000u; \
+    const bool oky_ = (valid) & ((unsigned)((t).y0 - 1 + 2 * (k) + s_pyw) < (unsigned)a.H);      /* scalar */        \
+    const unsigned off_ = (oky_ & (okx)) ? (trel) + ((org) + (unsigned)((k) * row2_bytes)) : 0x80000000u;          \
     if (WINO_AB(1)) dst = u32x4{off_, 0u, 0u, 0u};                                                                 \
     else dst = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off_, 0, 0);                                            \
   } while (0)
+#define WINO_STAGE_TERMS(t)                                                                                        \
+  WINO_SLOT(sl_);                                                                                                  \
+  const int px_ = sl_ & 31;                                                                                        \
+  const unsigned trel_ = (unsigned)((s_pyw * a.W + px_) * xp + 4 * sc4) * 4u;                                      \
+  const bool okx_ = (unsigned)((t).x0 - 1 + px_) < (unsigned)a.W
   // the region travels in two halves through the SAME three registers (rounds 0..2, then 3..5): 12 instead of 24 live
-#define WINO_STAGE_LOAD_A(t, c, valid)    \
-  do {                                    \
-    WINO_STAGE_ONE(st0, 0, t, c, valid);  \
-    WINO_STAGE_ONE(st1, 1, t, c, valid);  \
-    WINO_STAGE_ONE(st2, 2, t, c, valid);  \
+#define WINO_STAGE_LOAD_A(t, c, valid)                       \
+  do {                                                       \
+    const unsigned org_ = WINO_STAGE_ORIGIN(t, c);           \
+    WINO_STAGE_TERMS(t);                                     \
+    WINO_STAGE_ROW(st0, 0, t, org_, valid, trel_, okx_);     \
+    WINO_STAGE_ROW(st1, 1, t, org_, valid, trel_, okx_);     \
+    WINO_STAGE_ROW(st2, 2, t, org_, valid, trel_, okx_);     \
   } while (0)
-#define WINO_STAGE_LOAD_B(t, c, valid)    \
-  do {                                    \
-    WINO_STAGE_ONE(st0, 3, t, c, valid);  \
-    WINO_STAGE_ONE(st1, 4, t, c, valid);  \
-    WINO_STAGE_ONE(st2, 5, t, c, valid);  \
+#define WINO_STAGE_LOAD_B(t, c, valid)                                                                             \
+  do {                                                                                                             \
+    const unsigned org_ = WINO_STAGE_ORIGIN(t, c);                                                                 \
+    WINO_STAGE_TERMS(t);                                                                                           \
+    WINO_STAGE_ROW(st0, 3, t, org_, valid, trel_, okx_);                                                           \
+    WINO_STAGE_ROW(st1, 4, t, org_, valid, trel_, okx_);                                                           \
+    const int rpy_ = sl_ >> 1, rpx_ = 32 + (sl_ & 1);               /* round 5: columns 32, 33 of the ten rows */  \
+    const bool okr_ = (valid) & (sl_ < 20) & ((unsigned)((t).y0 - 1 + rpy_) < (unsigned)a.H) &                     \
+                      ((unsigned)((t).x0 - 1 + rpx_) < (unsigned)a.W);                                              \
+    const unsigned offr_ = okr_ ? (unsigned)((rpy_ * a.W + rpx_) * xp + 4 * sc4) * 4u + org_ : 0x80000000u;        \
+    if (WINO_AB(1)) st2 = u32x4{offr_, 0u, 0u, 0u};                                                                \
+    else st2 = __builtin_amdgcn_raw_buffer_load_b128(xsrd, offr_, 0, 0);                                           \
   } while (0)
   // channel 4 c4 + i of pixel p goes to word p * 17 + 4 i + c4 (k-step i reads word 4 i + q)
-#define WINO_PARK_ONE(buf, src, k)                            \
+#define WINO_PARK_AT(dptr, src)                               \
   do {                                                        \
-    float* d_ = (buf) + (sp0 + 64 * (k)) * kWPP + sc4;        \
+    float* d_ = (dptr);                                       \
     if (WINO_AB(2) && src.x != 0x7fc12345u) break;            \
     d_[0] = __uint_as_float(src.x);                           \
     d_[4] = __uint_as_float(src.y);                           \
     d_[8] = __uint_as_float(src.z);                           \
     d_[12] = __uint_as_float(src.w);                          \
   } while (0)
-#define WINO_STAGE_WRITE_A(buf)                               \
-  do {                                                        \
-    WINO_PARK_ONE(buf, st0, 0);                               \
-    WINO_PARK_ONE(buf, st1, 1);                               \
-    WINO_PARK_ONE(buf, st2, 2);                               \
+#define WINO_STAGE_WRITE_A(buf)                                                     \
+  do {                                                                              \
+    WINO_SLOT(sl_);                                                                 \
+    float* b_ = (buf) + ((s_pyw * kWRegW) + (sl_ & 31)) * kWPP + sc4;               \
+    WINO_PARK_AT(b_ + 0 * 2 * kWRegW * kWPP, st0);                                  \
+    WINO_PARK_AT(b_ + 1 * 2 * kWRegW * kWPP, st1);                                  \
+    WINO_PARK_AT(b_ + 2 * 2 * kWRegW * kWPP, st2);                                  \
   } while (0)
-#define WINO_STAGE_WRITE_B(buf)                               \
-  do {                                                        \
-    WINO_PARK_ONE(buf, st0, 3);                               \
-    WINO_PARK_ONE(buf, st1, 4);                               \
-    if (sp0 + 320 < kWRegPix) WINO_PARK_ONE(buf, st2, 5);     \
+#define WINO_STAGE_WRITE_B(buf)                                                     \
+  do {                                                                              \
+    WINO_SLOT(sl_);                                                                 \
+    float* b_ = (buf) + ((s_pyw * kWRegW) + (sl_ & 31)) * kWPP + sc4;               \
+    WINO_PARK_AT(b_ + 3 * 2 * kWRegW * kWPP, st0);                                  \
+    WINO_PARK_AT(b_ + 4 * 2 * kWRegW * kWPP, st1);                                  \
+    if (sl_ < 20) WINO_PARK_AT((buf) + ((sl_ >> 1) * kWRegW + 32 + (sl_ & 1)) * kWPP + sc4, st2); \
   } while (0)
 
   // ---- weights: the slices of consecutive k-steps are consecutive, cyclically over the block's items (cout tile fastest).
