@@ -396,3 +396,45 @@ def test_conv_cl_supported_mirrors_the_kernel_limits():
     assert not ops.conv_cl_supported(cl(4, 64, 64, 64), 64, (3, 3), stride=3)
     wide = torch.empty((44, 256, 256, 192), device="meta").permute(0, 3, 1, 2)[:, :64]   # a channel slice: the PITCH counts
     assert not ops.conv_cl_supported(wide, 64, (3, 3))
+
+
+def test_conv_wino_prepare_operand_order_reproduces_the_convolution():
+    """Host logic of the Winograd path without a GPU: ops.conv_wino_prepare packs U = G w G^T in the operand order
+    include/smos.h documents; unpacking that block with the documented index formula and running F(2x2, 3x3) in numpy
+    (B^T d B, 16 channel sums, A^T M A) must give conv2d.  Pins the packing independently of the kernel."""
+    import torch.nn.functional as F
+    from streammos_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for cin, cout, mb in ((16, 16, 1), (32, 64, 2), (48, 32, 1)):
+        w = torch.randn((cout, cin, 3, 3), generator=gen, dtype=torch.float32)
+        packed = ops.conv_wino_prepare(w, mb).numpy()
+        assert packed.size == 16 * cout * cin
+        # wprep[((((ct * (Cin/16) + cc) * 4 + i) * mb + m) * 4 + xi) * 64 + lane][nu] = U[xi][nu] of
+        # w[ct*16*mb + m*16 + (lane & 15)][cc*16 + 4*(lane >> 4) + i]
+        blk = packed.reshape(cout // (16 * mb), cin // 16, 4, mb, 4, 64, 4)
+        u = np.zeros((cout, cin, 4, 4), dtype=np.float64)
+        for lane in range(64):
+            for i in range(4):
+                co = np.arange(cout // (16 * mb))[:, None] * 16 * mb + np.arange(mb)[None, :] * 16 + (lane & 15)      # [ct, m]
+                ci = np.arange(cin // 16) * 16 + 4 * (lane >> 4) + i                                                   # [cc]
+                u[co[:, None, :], ci[None, :, None]] = blk[:, :, i, :, :, lane, :].transpose(0, 1, 2, 3, 4)
+        g = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]])
+        want_u = np.einsum("ij,ocjk,lk->ocil", g, w.numpy().astype(np.float64), g)
+        assert np.abs(u - want_u).max() <= 1e-6 * np.abs(want_u).max()                 # float32 rounding of the float64 transform
+        x = torch.randn((2, cin, 6, 8), generator=gen)
+        bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+        at = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+        xp = np.pad(x.numpy().astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)))
+        out = np.zeros((2, cout, 6, 8))
+        for ty in range(3):
+            for tx in range(4):
+                d = xp[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+                v = np.einsum("ij,bcjk,lk->bcil", bt, d, bt)
+                m = np.einsum("ocil,bcil->boil", u, v)
+                out[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ij,bojk,lk->boil", at, m, at)
+        want = F.conv2d(x.double(), w.double(), None, 1, 1).numpy()
+        assert np.abs(out - want).max() <= 1e-5 * np.abs(want).max(), (cin, cout, mb)
+    with pytest.raises(RuntimeError):
+        ops.conv_wino_prepare(torch.zeros(32, 32, 5, 3), 2)          # not a 3x3 kernel
+    with pytest.raises(RuntimeError):
+        ops.conv_wino_prepare(torch.zeros(16, 32, 3, 3), 2)          # Cout not a multiple of 16 * mb
