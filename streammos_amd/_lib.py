@@ -94,6 +94,7 @@ def load():
     lib.smos_dbscan_work_bytes.restype = ctypes.c_int64
     lib.smos_stem_scan_state_words.restype = ctypes.c_int64
     lib.smos_conv_cl_sum_chunks.restype = ctypes.c_int64
+    lib.smos_conv_wino_sum_chunks.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p

@@ -919,7 +919,8 @@ def test_conv_wino_cl_is_deterministic_and_batch_independent():
     assert torch.equal(a, b) and torch.equal(a[1:2], c)
 
 
-@pytest.mark.parametrize("cin,cout,hw,mb", [(32, 32, (40, 64), 2), (64, 64, (13, 45), 2), (128, 128, (16, 32), 1), (32, 32, (3, 8), 1)])
+@pytest.mark.parametrize("cin,cout,hw,mb", [(32, 32, (40, 64), 2), (64, 64, (13, 45), 2), (128, 128, (16, 32), 1), (32, 32, (3, 8), 1),
+                                            (32, 32, (24, 40), 2)])
 def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb):
     """conv_wino_cl(chan_sums=...): channel sums per (8-row x 32-column block, tile row) in a fixed order; the ChannelAtt gate
     (networks/backbone.py:57-73, 87-102) built on them equals float64."""
