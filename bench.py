@@ -82,6 +82,12 @@ def algorithmic_bytes(label, ctx=None):
         # direct-conv part in, the two sources' x-pass rows in (the network's geometry: half and quarter height), map out
         b, ho, wo, c = (int(v) for v in dims.split("x"))
         return 4 * (2 * b * ho * wo * c + b * 3 * (ho // 2 + ho // 4) * wo * c)
+    if name == "upconv_xy":
+        # both passes in one launch: the sources' tap products z [B, Hs, Ws, 9 C] and the direct-conv part in, the map out
+        dst, srcs = dims.split("<-")
+        b, ho, wo, c = (int(v) for v in dst.split("x"))
+        cells = sum(int(hw.split("x")[0]) * int(hw.split("x")[1]) for hw in srcs.split("+"))
+        return 4 * (2 * b * ho * wo * c + b * cells * 9 * c)
     if name == "conv_cl":
         # own implicit-GEMM conv (csrc/conv_igemm.hip): label B x Cin x H x W -> Cout x Ho x Wo k KHxKW [+res]
         geo = _conv_geometry(dims)
@@ -128,6 +134,30 @@ def algorithmic_flops(label, ctx=None):
         geo = _conv_geometry(dims)
         return 2 * geo["b"] * geo["ho"] * geo["wo"] * geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"]
     return 0
+
+
+def event_bracket_overhead(device, n=64):
+    """ms an (event, launch, event) bracket adds to the launch it times, measured on a device copy of ~30 us."""
+    src = torch.empty(48 << 20, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    for _ in range(4):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    each = []
+    for _ in range(n):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        dst.copy_(src)
+        eb.record()
+        each.append((ea, eb))
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea.record()
+    for _ in range(n):
+        dst.copy_(src)
+    eb.record()
+    torch.cuda.synchronize()
+    per = sorted(a.elapsed_time(b) for a, b in each)[n // 2]
+    return max(0.0, per - ea.elapsed_time(eb) / n)
 
 
 def executed_launch_flops(label, wino=True):
@@ -533,17 +563,11 @@ def main():
                 for i in range(8):
                     serial.step(*dev_frames[(2 + i) % len(dev_frames)])
             ser = kt_ser.summary().get(dominant)
-            # what an (event, launch, event) bracket adds to a launch: the same bracket around nothing, on the same stream
-            # (the two event packets' own processing; ~7 % of a 40 us launch).  Subtracted, and reported.
-            pairs = []
-            for _ in range(64):
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record()
-                eb.record()
-                pairs.append((ea, eb))
-            torch.cuda.synchronize()
-            gaps = sorted(ea.elapsed_time(eb) for ea, eb in pairs)
-            bracket_ms = gaps[len(gaps) // 2]
+            # what an (event, launch, event) bracket adds to a launch (the event packets' own processing; ~7 % of a 40 us
+            # launch): a ~30 us device copy 64 times, every launch in its own bracket vs. all 64 in ONE bracket (the queue
+            # never drains: the copies run back to back).  Subtracted, and reported.  (Two records with nothing between them
+            # are no measure of it: 2.7 us on one box, 10.8 us on the next.)
+            bracket_ms = event_bracket_overhead(device)
             if ser is not None:
                 iso = max(ser[2] - bracket_ms, 1e-6)
                 roof["event_bracket_ms"] = round(bracket_ms, 5)
@@ -559,6 +583,13 @@ def main():
                     roof["achieved"], roof["frac"] = round(ach, 1), round(ach / HBM_PEAK_GBS, 4)
                 roof["avg_launch_ms"] = round(iso, 4)
                 roof["launches"] = ser[0]
+                if roof["bound"] == "mfma":
+                    # `achieved` counts the ALGORITHMIC FLOPs of the layer (2 x 9 multiply-adds per output and channel pair for a
+                    # 3x3 convolution); a Winograd launch issues 4/9 of them, so its algorithmic rate may pass the dense peak.
+                    # What the matrix cores really did:
+                    ex = executed_launch_flops(dominant, wino=getattr(eng, "wino", False))
+                    roof["executed_flops_per_launch"] = ex
+                    roof["executed_frac"] = round(ex / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
                 roof["clock"] = ("HIP events (torch.cuda.Event) on the launch stream around every launch of the dominant label in 8 "
                                  "serial steps (StreamRunner(pipeline=False): one stream) right after the timed region = what "
                                  "rocprofv3 --kernel-trace of `bench.py --no-pipeline` reports per launch "

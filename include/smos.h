@@ -297,7 +297,14 @@ int smos_conv_wino_cl(const float* x, int64_t x_pitch, const float* wprep, const
  *   smos_upconv_ypass  out [B, Ho, Wo, *] (row pitch out_pitch) <- act(conv_a + bias + sum_src sum_ky up_y(t_src)[Y + ky - 1]);
  *                      conv_a [B, Ho, Wo, *] (row pitch a_pitch) is the direct convolution of the channels that are not
  *                      upsampled; t2 may be NULL; act 0 none, 1 ReLU, 2 LeakyReLU(0.01); interpolation with ATen's
- *                      align_corners=True weights. */
+ *                      align_corners=True weights.
+ *   smos_upconv_xy     the two passes in one launch, t kept in registers (same operations in the same order: same
+ *                      results): out <- act(conv_a + bias + sum over z1 [B, H1, W1, 9*C], z2 [B, H2, W2, 9*C] (one may
+ *                      be NULL)).  Only for sources of at most half the output height: smos_upconv_xy_ok(Hs, Ho) != 0. */
+int smos_upconv_xy_ok(int64_t Hs, int64_t Ho);
+int smos_upconv_xy(const float* conv_a, int64_t a_pitch, const float* bias, const float* z1, int64_t H1, int64_t W1, const float* z2,
+                   int64_t H2, int64_t W2, float* out, int64_t out_pitch, int64_t B, int64_t Ho, int64_t Wo, int64_t C, int32_t act,
+                   smos_stream_t stream);
 int smos_upconv_xpass(const float* z, float* t, int64_t B, int64_t Hs, int64_t Ws, int64_t C, int64_t Wo, smos_stream_t stream);
 int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const float* bias, const float* t1, int64_t H1, const float* t2,
                       int64_t H2, float* out, int64_t out_pitch, int64_t B, int64_t Ho, int64_t Wo, int64_t C, int32_t act,

@@ -9,6 +9,7 @@ KIND = (
     (("stem_epilogue",), "stem_epilogue[", 1),
     (("upconv_xpass",), "upconv_xpass[", 1),
     (("upconv_ypass", "upconv_fused"), "upconv_ypass[", 1),
+    (("upconv_xy",), "upconv_xy[", 1),
     (("msda_fwd",), "msda_fwd[", 1),
     (("stem_mark", "stem_scan"), "stem_mark+scan[", 2),
 )

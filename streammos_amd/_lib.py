@@ -53,6 +53,8 @@ SIGNATURES = {
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_upconv_ypass": [vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
+    "smos_upconv_xy_ok": [i64, i64],
+    "smos_upconv_xy": [vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_gather_scatter": [vp, c_i64p, vp, i32, c_f32p, vp, i32, c_f32p, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_nhwc_to_nchw": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_prep_transform_mask": [vp, i64, c_f64p, c_f64p, vp, vp, vp],

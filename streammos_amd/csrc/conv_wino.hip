@@ -27,8 +27,9 @@
 //                immediate offsets) are then bank-conflict free (bank = 2 tx + q + const).  Per k-step a lane reads its 4x4
 //                patch, runs the 32 additions of B^T d B and owns the 16 B operands.  Two region buffers: chunk g + 1 is
 //                requested at the start of chunk g and written during its last k-step.
-//   A operand  = U, streamed through a two-slot LDS ring, one k-step (16 x 16 MB x 4 floats) per slot, requested a k-step
-//                ahead; a lane reads 4 consecutive (nu) operands per ds_read_b128.  One barrier per k-step.
+//   A operand  = U, streamed through a three-slot LDS ring by LDS-DMA (no registers on the way), one k-step (16 x 16 MB x 4
+//                floats) per slot, requested two k-steps ahead; a lane reads 4 consecutive (nu) operands per ds_read_b128.
+//                One barrier per k-step.
 //   bytes      = per cin: 64 B x 16 MB of weights + ~85 B x 16 of activations for 16 x 16 MB x 64 MACs: 13 B/clk/CU at
 //                MB = 2 with the matrix pipe saturated -- inside what an XCD's L2 serves a CU (~29 B/clk).
 #include <stdlib.h>

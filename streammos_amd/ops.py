@@ -730,6 +730,8 @@ def upconv_tap_weights(w, c0, c1):
 # The nine tap products: library GEMM by default; "conv" runs them on the own kernel as one 1x1 convolution with 9*C outputs
 # (measured in the step: 236.6 vs 238.8 scans/s -- K = 128 is only four stages per tile, so the epilogue dominates).
 _TAP_GEMM_OWN = os.environ.get("SMOS_TAP_GEMM", "mm") == "conv"
+# x pass and y pass in one launch (smos_upconv_xy) where the geometry allows; "0": always the two launches (A/B, same results)
+_UPCONV_XY = os.environ.get("SMOS_UPCONV_XY", "1") != "0"
 
 
 def upconv3x3(conv_a, bias, sources, act, out=None):
@@ -742,7 +744,10 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
         out = conv_a
     lib = _lib.load()
     st = _stream(conv_a)
-    ts = []
+    if not 1 <= len(sources) <= 2:
+        raise RuntimeError("upconv3x3: one or two upsampled sources, got %d" % len(sources))
+    fused = _UPCONV_XY and all(lib.smos_upconv_xy_ok(x.shape[2], ho) for x, _ in sources)
+    zs, ts = [], []
     with torch.cuda.device(conv_a.device):
         for x, wt in sources:
             hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
@@ -756,10 +761,21 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
                 # the library picks a faster kernel for this form than for mm(rows, nk.t()) (tools/ubench_tapgemm.py:
                 # 0.182 vs 0.207 ms at 65536 x 128 x 1152); adding 0 changes no value
                 z = torch.addmm(wt.zero, rows, wt.kn)
+            zs.append((z, hs, ws))
+            if fused:
+                continue
             t = torch.empty((b, 3, hs, wo, c), dtype=torch.float32, device=conv_a.device)
             with profiling.span("upconv_xpass[%dx%dx%dx%d->%d]" % (b, hs, ws, c, wo)):
                 _lib.check(lib.smos_upconv_xpass(z.data_ptr(), t.data_ptr(), b, hs, ws, c, wo, st), "smos_upconv_xpass")
             ts.append((t, hs))
+        if fused:
+            z1, h1, w1 = zs[0]
+            z2, h2, w2 = zs[1] if len(zs) > 1 else (None, 0, 0)
+            with profiling.span("upconv_xy[%dx%dx%dx%d<-%s]" % (b, ho, wo, c, "+".join("%dx%d" % (h, w) for _, h, w in zs))):
+                _lib.check(lib.smos_upconv_xy(conv_a.data_ptr(), _cl("upconv3x3", conv_a), bias.data_ptr(), z1.data_ptr(), h1, w1,
+                                              z2.data_ptr() if z2 is not None else None, h2, w2, out.data_ptr(), _cl("upconv3x3", out),
+                                              b, ho, wo, c, int(act), st), "smos_upconv_xy")
+            return out
         t1, h1 = ts[0]
         t2, h2 = ts[1] if len(ts) > 1 else (None, 0)
         with profiling.span("upconv_ypass[%dx%dx%dx%d]" % (b, ho, wo, c)):

@@ -316,14 +316,18 @@ def test_point_head_against_float64_reference(b, n, m3):
     assert (out.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("ho,wo,sizes", [(64, 48, ((32, 24), (16, 12))), (40, 40, ((20, 20),)), (33, 47, ((9, 13), (5, 6)))])
-def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes):
+@pytest.mark.parametrize("ho,wo,sizes,cout", [(64, 48, ((32, 24), (16, 12)), 32), (40, 40, ((20, 20),), 32), (33, 47, ((9, 13), (5, 6)), 32),
+                                              (20, 24, ((15, 12), (5, 6)), 32),        # a source taller than half the output: two launches
+                                              (256, 256, ((128, 128), (64, 64)), 128),   # the network's geometry: 32-row strips
+                                              (1, 9, ((1, 4),), 32), (70, 8, ((3, 3), (35, 4)), 32)])
+def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes, cout, monkeypatch):
     """conv3x3(cat(x0, up(x1), up(x2))) + bias + LeakyReLU computed as direct conv on x0 + tap GEMMs at source resolution
-    + separable interpolation passes, against the direct form in float64.  Odd sizes exercise the align_corners ratios
-    and the image borders (taps leaving the upsampled image must be dropped, not clamped)."""
+    + separable interpolation (one launch, or x pass + y pass), against the direct form in float64.  Odd sizes exercise
+    the align_corners ratios and the image borders (taps leaving the upsampled image must be dropped, not clamped).  The
+    one-launch form runs the same operations in the same order as the pair: equal bits."""
     import torch.nn.functional as F
     gen = torch.Generator(device="cpu").manual_seed(43)
-    b, c0, cs, cout = 2, 8, 16, 32
+    b, c0, cs = 2, 8, 16
     x0 = torch.randn((b, c0, ho, wo), generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
     xs = [torch.randn((b, cs) + hw, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last) for hw in sizes]
     cin = c0 + cs * len(xs)
@@ -334,8 +338,11 @@ def test_upconv3x3_equals_conv_of_upsampled_concat(ho, wo, sizes):
     conv_a = F.conv2d(x0, w[:, :c0].contiguous(memory_format=torch.channels_last), None, 1, 1)
     assert conv_a.is_contiguous(memory_format=torch.channels_last)
     srcs = [(x, ops.upconv_tap_weights(w, c0 + i * cs, c0 + (i + 1) * cs)) for i, x in enumerate(xs)]
-    got = ops.upconv3x3(conv_a, bias, srcs, 2)
+    got = ops.upconv3x3(conv_a.clone(), bias, srcs, 2)
     assert (got.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    monkeypatch.setattr(ops, "_UPCONV_XY", False)
+    assert torch.equal(got, ops.upconv3x3(conv_a.clone(), bias, srcs, 2))
+    monkeypatch.setattr(ops, "_UPCONV_XY", True)
     # other weights at (very likely) the same addresses: nothing derived from the first set may survive in a cache
     # keyed by a weight's address (a freed model's memory is handed to the next model by the caching allocator)
     ptr = w.data_ptr()
