@@ -26,7 +26,29 @@ def set_workspace_namespace(tag):
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """raw handle of torch's current HIP stream on t's device (the C call behind torch.cuda.current_stream(...).cuda_stream:
+    the wrapper objects cost ~4 us per launch on the host)."""
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
+
+
+class _NoGuard:
+    """`with` target for a launch on the device that is already current: nothing to switch, nothing to restore."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for a launch: torch.cuda.device(...) only where the tensor's device is not the current one (the usual
+    one-process-per-GPU case never switches; the guard object and its two device queries cost ~3 us per launch)."""
+    return _NO_GUARD if torch._C._cuda_getDevice() == device.index else torch.cuda.device(device)
 
 
 def _require_cuda(name, *tensors):
@@ -70,7 +92,7 @@ def voxel_maxpool_fwd(feat, ind, out, out_size, scale, voxel_max_idx=None):
         raise RuntimeError("voxel_maxpool_fwd: voxel_max_idx must be contiguous int64")
     lib = _lib.load()
     label = "voxel_maxpool_fwd[%dx%dx%d->%s]" % (bs, c, n, "x".join(str(int(s)) for s in out_size))
-    with torch.cuda.device(feat.device), profiling.span(label):
+    with _on(feat.device), profiling.span(label):
         rc = lib.smos_voxel_maxpool_fwd(
             feat.data_ptr(), _lib.i64_array(feat.stride()[:3]), ind.data_ptr(), out.data_ptr(),
             _lib.i64_array(out.stride()), voxel_max_idx.data_ptr() if voxel_max_idx is not None else None,
@@ -94,7 +116,7 @@ def voxel_maxpool_bwd(feat, ind, out, grad_out, grad_feat, out_size, scale):
         raise RuntimeError("voxel_maxpool_bwd: grad_feat layout must match feat")
     bs, c, n = feat.shape[0], feat.shape[1], feat.shape[2]
     lib = _lib.load()
-    with torch.cuda.device(feat.device):
+    with _on(feat.device):
         rc = lib.smos_voxel_maxpool_bwd(
             feat.data_ptr(), _lib.i64_array(feat.stride()[:3]), ind.data_ptr(), out.data_ptr(), grad_out.data_ptr(),
             _lib.i64_array(out.stride()), grad_feat.data_ptr(), bs, c, n, ind.shape[2], _lib.i64_array(out_size),
@@ -121,7 +143,7 @@ def bilinear_gather(grid, coord, scale, out=None, point_major=False):
         else:
             out = torch.empty((b, c, n), dtype=torch.float32, device=grid.device)
     lib = _lib.load()
-    with torch.cuda.device(grid.device), profiling.span("bilinear_gather[%dx%dx%dx%d->%d]" % (b, c, h, w, n)):
+    with _on(grid.device), profiling.span("bilinear_gather[%dx%dx%dx%d->%d]" % (b, c, h, w, n)):
         rc = lib.smos_bilinear_gather_fwd(grid.data_ptr(), _lib.i64_array(grid.stride()), coord.data_ptr(), k,
                                           out.data_ptr(), _lib.i64_array(out.stride()[:3]), b, c, h, w, n,
                                           _lib.f32_array(scale), _stream(grid))
@@ -141,7 +163,7 @@ def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
     lq, l, p = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
     out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
     lib = _lib.load()
-    with torch.cuda.device(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+    with _on(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, lq, m, d)):
         rc = lib.smos_msda_fwd(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), n, s, m, d, l, lq, p,
                                _dtype_code("ms_deform_attn_forward", value), _stream(value))
@@ -161,7 +183,7 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
     g_loc = torch.empty_like(sampling_loc)
     g_attn = torch.empty_like(attn_weight)
     lib = _lib.load()
-    with torch.cuda.device(value.device), profiling.span("msda_bwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+    with _on(value.device), profiling.span("msda_bwd[%dx%dx%dx%d]" % (n, lq, m, d)):
         rc = lib.smos_msda_bwd(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                sampling_loc.data_ptr(), attn_weight.data_ptr(), g_value.data_ptr(), g_loc.data_ptr(),
                                g_attn.data_ptr(), n, s, m, d, l, lq, p, _dtype_code("ms_deform_attn_backward", value),
@@ -180,7 +202,7 @@ def tta_argmax(pred, want_prob=False):
     labels = torch.empty(n, dtype=torch.uint8, device=pred.device)
     prob = torch.empty((n, k), dtype=torch.float32, device=pred.device) if want_prob else None
     lib = _lib.load()
-    with torch.cuda.device(pred.device):
+    with _on(pred.device):
         rc = lib.smos_tta_argmax(pred.data_ptr(), b, k, n, labels.data_ptr(), prob.data_ptr() if want_prob else None,
                                  _stream(pred))
     _lib.check(rc, "smos_tta_argmax")
@@ -190,7 +212,7 @@ def tta_argmax(pred, want_prob=False):
 def vote_clear(table):
     _require_cuda("vote_clear", table)
     lib = _lib.load()
-    with torch.cuda.device(table.device):
+    with _on(table.device):
         rc = lib.smos_vote_clear(table.data_ptr(), _stream(table))
     _lib.check(rc, "smos_vote_clear")
 
@@ -204,7 +226,7 @@ def vote_accumulate(points, labels, table, pose_diff=None, recip_quantize=False)
     if pose_diff is not None:
         pose = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _on(points.device):
         rc = lib.smos_vote_accumulate(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(), pose,
                                       1 if recip_quantize else 0, table.data_ptr(), _stream(points))
     _lib.check(rc, "smos_vote_accumulate")
@@ -232,7 +254,7 @@ def vote_accumulate_frames(frames, table, recip_quantize=False):
             keep.append(arr)
             pose[f] = ctypes.cast(arr, _lib.c_f64p)
     lib = _lib.load()
-    with torch.cuda.device(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
+    with _on(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
         rc = lib.smos_vote_accumulate_frames(count, pts, n, stride, lab, pose, 1 if recip_quantize else 0, table.data_ptr(),
                                              torch.cuda.current_stream(table.device).cuda_stream)
     _lib.check(rc, "smos_vote_accumulate_frames")
@@ -242,7 +264,7 @@ def vote_resolve(points, labels, table, lut=None, recip_quantize=False):
     _require_cuda("vote_resolve", points, labels, table, lut)
     out = torch.empty(points.shape[0], dtype=torch.int32, device=points.device)
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _on(points.device):
         rc = lib.smos_vote_resolve(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(),
                                    1 if recip_quantize else 0, table.data_ptr(),
                                    lut.data_ptr() if lut is not None else None, out.data_ptr(), _stream(points))
@@ -267,7 +289,7 @@ def dbscan(points, eps, min_samples, max_sweeps=4096):
         raise RuntimeError("dbscan: workspace query failed for n=%d" % n)
     work = torch.empty(need + 256, dtype=torch.uint8, device=points.device)
     base = (work.data_ptr() + 255) // 256 * 256
-    with torch.cuda.device(points.device):
+    with _on(points.device):
         rc = lib.smos_dbscan(points.data_ptr(), n, points.stride(0), float(eps), int(min_samples), labels.data_ptr(),
                              base, need, int(max_sweeps), _stream(points))
     _lib.check(rc, "smos_dbscan")
@@ -288,7 +310,7 @@ def box_vote(points, labels, boxes, counts, pose_diff=None):
     if pose_diff is not None:
         pose = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _on(points.device):
         rc = lib.smos_box_vote(points.data_ptr(), points.shape[0], points.stride(0), labels.data_ptr(), pose,
                                boxes.data_ptr(), boxes.shape[0], counts.data_ptr(), _stream(points))
     _lib.check(rc, "smos_box_vote")
@@ -320,7 +342,7 @@ def bias_act(x, bias, act, out=None, residual=None):
     if residual is not None:
         rb, rc, _ = _planes("bias_act", residual)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc_ = lib.smos_bias_act(x.data_ptr(), xb, xc, bias.data_ptr() if bias is not None else None,
                                 residual.data_ptr() if residual is not None else None, rb, rc, out.data_ptr(), ob, oc,
                                 x.shape[0], x.shape[1], hw, act, _stream(x))
@@ -335,7 +357,7 @@ def downsample_epilogue(a, p, bias, stride, out=None):
         out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
     ob, oc, _ = _planes("downsample_epilogue", out)
     lib = _lib.load()
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         rc = lib.smos_downsample_epilogue(a.data_ptr(), _lib.i64_array(a.stride()), p.data_ptr(), _lib.i64_array(p.stride()),
                                           bias.data_ptr(), out.data_ptr(), ob, oc, p.shape[0], p.shape[1], p.shape[2],
                                           p.shape[3], stride, _stream(a))
@@ -351,7 +373,7 @@ def channel_gate_residual(y, bias, w1, b1, w2, b2, xres, sums_ws, out=None):
     rb, rc, _ = _planes("channel_gate_residual", xres)
     ob, oc, _ = _planes("channel_gate_residual", out)
     lib = _lib.load()
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc_ = lib.smos_channel_gate_residual(y.data_ptr(), yb, yc, bias.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                              w2.data_ptr(), b2.data_ptr(), xres.data_ptr(), rb, rc, out.data_ptr(), ob, oc,
                                              sums_ws.data_ptr(), y.shape[0], y.shape[1], w1.shape[0], hw, _stream(y))
@@ -370,7 +392,7 @@ def upsample_concat(sources, size, out=None):
     strides = [_planes("upsample_concat", s) for s in sources]
     ptrs = (ctypes.c_void_p * len(sources))(*[s.data_ptr() for s in sources])
     lib = _lib.load()
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         rc = lib.smos_upsample_concat(ptrs, _lib.i64_array([s.shape[1] for s in sources]),
                                       _lib.i64_array([s.shape[2] for s in sources]),
                                       _lib.i64_array([s.shape[3] for s in sources]),
@@ -406,7 +428,7 @@ def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None, zero_fill=F
     if pts_out is not None:
         po_b, po_n = _rows("pointnet_scatter", pts_out, cout)
     lib = _lib.load()
-    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, h, w)):
+    with _on(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, h, w)):
         if zero_fill:
             bev.zero_()
         rc = lib.smos_pointnet_scatter(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
@@ -453,7 +475,7 @@ def point_head(rows, wprep, m3, out=None):
     if out is None:
         out = torch.empty((b, m3, n), dtype=torch.float32, device=rows.device)
     lib = _lib.load()
-    with torch.cuda.device(rows.device), profiling.span("point_head[%dx%d]" % (b, n)):
+    with _on(rows.device), profiling.span("point_head[%dx%d]" % (b, n)):
         rc = lib.smos_point_head(rows.data_ptr(), rows.stride(1), wprep.data_ptr(), out.data_ptr(), b, n, 192, 96, 64, m3,
                                  _stream(rows))
     _lib.check(rc, "smos_point_head")
@@ -530,14 +552,14 @@ def conv_rows_cl(x, wprep, bias, act, cout, kernel, mt=1, residual=None, out=Non
             residual.data_ptr() if residual is not None else None, _cl("conv_rows_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_rows_cl", out), b, h, w, cin, cout, kh, kw, int(mt), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
-    with torch.cuda.device(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label):
         rc = lib.smos_conv_rows_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_rows_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)
 
         def again(keep=keep):
-            with torch.cuda.device(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label):
                 _lib.check(lib.smos_conv_rows_cl(*args, _stream(keep[0])), "smos_conv_rows_cl")
         profiling.offer_replay(label, again)
     return out
@@ -589,14 +611,14 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
             residual.data_ptr() if residual is not None else None, _cl("conv_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
-    with torch.cuda.device(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label):
         rc = lib.smos_conv_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)          # the closure keeps the operands alive
 
         def again(keep=keep):
-            with torch.cuda.device(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label):
                 _lib.check(lib.smos_conv_cl(*args, _stream(keep[0])), "smos_conv_cl")
         profiling.offer_replay(label, again)
     return out
@@ -661,14 +683,14 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
             out.data_ptr(), _cl("conv_wino_cl", out), b, h, w, cin, cout, int(mb), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
     fn = lib.smos_conv_wino_cl
-    with torch.cuda.device(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label):
         rc = fn(*args, _stream(x))
     _lib.check(rc, "smos_conv_wino_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)
 
         def again(keep=keep):
-            with torch.cuda.device(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label):
                 _lib.check(fn(*args, _stream(keep[0])), "smos_conv_wino_cl")
         profiling.offer_replay(label, again)
     return out
@@ -682,7 +704,7 @@ def msda_fwd_qp(value, qp, h, w, points):
         raise RuntimeError("msda_fwd_qp: expected contiguous float32 value [N,H*W,M,D] and qp [N,H*W,M*P*3]")
     out = torch.empty((n, s, m * d), dtype=torch.float32, device=value.device)
     lib = _lib.load()
-    with torch.cuda.device(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, s, m, d)):
+    with _on(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, s, m, d)):
         rc = lib.smos_msda_fwd_qp(value.data_ptr(), qp.data_ptr(), out.data_ptr(), n, h, w, m, d, points, _stream(value))
     _lib.check(rc, "smos_msda_fwd_qp")
     return out
@@ -696,7 +718,7 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     c = x.shape[-1]
     out = torch.empty_like(x)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.smos_add_layer_norm(x.data_ptr(), res.data_ptr() if res is not None else None, gamma.data_ptr(), beta.data_ptr(),
                                      out.data_ptr(), x.numel() // c, c, float(eps), _stream(x))
     _lib.check(rc, "smos_add_layer_norm")
@@ -748,7 +770,7 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
         raise RuntimeError("upconv3x3: one or two upsampled sources, got %d" % len(sources))
     fused = _UPCONV_XY and all(lib.smos_upconv_xy_ok(x.shape[2], ho) for x, _ in sources)
     zs, ts = [], []
-    with torch.cuda.device(conv_a.device):
+    with _on(conv_a.device):
         for x, wt in sources:
             hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
             if wt.cin != cin or wt.cout != c:
@@ -912,7 +934,7 @@ def stem_plan(coord, h, w, row_floats=0):
         # capacity: an occupied cell holds at least one point, so min(cells, points) rows always suffice
         rows = _stream_workspace("stem_rows", (min(cells, b * t * n), row_floats), torch.float32, dev)
     st = _stream(coord)
-    with torch.cuda.device(dev), profiling.span("stem_mark+scan[%dx%dx%d]" % (b, h, w)):
+    with _on(dev), profiling.span("stem_mark+scan[%dx%dx%d]" % (b, h, w)):
         _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), state.data_ptr(), st), "smos_stem_mark")
         _lib.check(lib.smos_stem_scan(flags.data_ptr(), b, h, w, state.data_ptr(), row_cell.data_ptr(), row_of.data_ptr(),
                                       meta.data_ptr(), rows.data_ptr() if rows is not None else None, row_floats, st), "smos_stem_scan")
@@ -938,7 +960,7 @@ def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
     lib = _lib.load()
     st = _stream(xyzi)
     # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
-    with torch.cuda.device(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
+    with _on(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
         rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                             b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
                                             pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
@@ -970,7 +992,7 @@ def sparse_downsample(src, plan, wprep, bias, compact, out=None):
     lib = _lib.load()
     st = _stream(src)
     tag = "[%dx%dx%dx%d]" % (b, h, w, cin)
-    with torch.cuda.device(dev):
+    with _on(dev):
         with profiling.span("stem_gemm" + tag):
             _lib.check(lib.smos_stem_gemm(src.data_ptr(), None if compact else plan.row_cell.data_ptr(), plan.meta.data_ptr(),
                                           w_ptrs, y_ptrs, cin, cout, st), "smos_stem_gemm")
@@ -996,7 +1018,7 @@ def gather_scatter(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts
         po_b, po_n = _rows("gather_scatter", pts_out, c)
     lib = _lib.load()
     label = "gather_scatter[%dx%dx%dx%d->%d->%dx%d]" % (b, c, hg, wg, n, ho, wo)
-    with torch.cuda.device(grid.device), profiling.span(label):
+    with _on(grid.device), profiling.span(label):
         rc = lib.smos_gather_scatter(grid.data_ptr(), _lib.i64_array(grid.stride()), gcoord.data_ptr(), kg,
                                      _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
                                      _lib.f32_array(sscale) if out is not None else None,
@@ -1014,7 +1036,7 @@ def nhwc_to_nchw(src, dst):
     if not src.is_contiguous() or tuple(dst.shape) != (b, c, h, w):
         raise RuntimeError("nhwc_to_nchw: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
     lib = _lib.load()
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         rc = lib.smos_nhwc_to_nchw(src.data_ptr(), dst.data_ptr(), db, dc, b, c, hw, _stream(src))
     _lib.check(rc, "smos_nhwc_to_nchw")
     return dst
@@ -1044,7 +1066,7 @@ def bias_act_cl(x, bias, act, out=None, residual=None):
     if out is None:
         out = empty_cl(b, c, h, w, x.device)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.smos_bias_act_cl(x.data_ptr(), _cl("bias_act_cl", x), bias.data_ptr() if bias is not None else None,
                                   residual.data_ptr() if residual is not None else None,
                                   _cl("bias_act_cl", residual) if residual is not None else 0, out.data_ptr(),
@@ -1059,7 +1081,7 @@ def downsample_epilogue_cl(a, p, bias, stride, out=None):
     if out is None:
         out = empty_cl(b, c, a.shape[2], a.shape[3], a.device)
     lib = _lib.load()
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         rc = lib.smos_downsample_epilogue_cl(a.data_ptr(), _cl("downsample_epilogue_cl", a), p.data_ptr(),
                                              _cl("downsample_epilogue_cl", p), bias.data_ptr(), out.data_ptr(),
                                              _cl("downsample_epilogue_cl", out), b, c, h, w, stride, _stream(a))
@@ -1073,7 +1095,7 @@ def channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xres, ws, out=None):
     if out is None:
         out = empty_cl(b, c, h, w, y.device)
     lib = _lib.load()
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc = lib.smos_channel_gate_residual_cl(y.data_ptr(), _cl("channel_gate_residual_cl", y), bias.data_ptr(), w1.data_ptr(),
                                                b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), xres.data_ptr(),
                                                _cl("channel_gate_residual_cl", xres), out.data_ptr(),
@@ -1093,7 +1115,7 @@ def channel_gate_apply_cl(y, bias, w1, b1, w2, b2, xres, chan_sums, gate_ws, out
     if out is None:
         out = empty_cl(b, c, h, w, y.device)
     lib = _lib.load()
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc = lib.smos_channel_gate_apply_cl(y.data_ptr(), _cl("channel_gate_apply_cl", y), bias.data_ptr(), w1.data_ptr(),
                                             b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), xres.data_ptr(),
                                             _cl("channel_gate_apply_cl", xres), out.data_ptr(), _cl("channel_gate_apply_cl", out),
@@ -1111,7 +1133,7 @@ def upsample_concat_cl(sources, size):
     out = empty_cl(b, ctot, size[0], size[1], sources[0].device)
     ptrs = (ctypes.c_void_p * len(sources))(*[s.data_ptr() for s in sources])
     lib = _lib.load()
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         rc = lib.smos_upsample_concat_cl(ptrs, _lib.i64_array([s.shape[1] for s in sources]),
                                          _lib.i64_array([s.shape[2] for s in sources]),
                                          _lib.i64_array([s.shape[3] for s in sources]),
@@ -1136,7 +1158,7 @@ def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, 
     lib = _lib.load()
     label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d%s]" % (b, c, hg, wg, n, ho, wo,
                                                           "+pts" if pts_out is not None and out is not None else "")
-    with torch.cuda.device(grid.device), profiling.span(label):
+    with _on(grid.device), profiling.span(label):
         rc = lib.smos_gather_scatter_cl(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
                                         _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
                                         _lib.f32_array(sscale) if out is not None else None,
