@@ -502,13 +502,21 @@ def main():
 
     sync()
     t0 = time.perf_counter()
+    half = args.steps // 2
+    e_mid, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with profiling.kernel_timer(only=dominant) as kt:
         for i in range(args.steps):
+            if i == half:
+                e_mid.record()                 # on the runner's main stream, behind step `half - 1`
             one_step(args.warmup + i)
+        e_end.record()
         enqueue = time.perf_counter() - t0     # host time to issue all steps (the GPU may still be running)
         sync()
         elapsed = time.perf_counter() - t0
     timed = kt.summary()
+    # the second half of the timed region alone: the shader clock is still ramping through the first steps of a short run
+    # (2.09 -> 2.38 GHz, tools/conv_stamps.py); reported beside ms_per_step, which stays the whole region
+    second_half_ms = e_mid.elapsed_time(e_end) / (args.steps - half) if args.steps - half > 0 and half > 0 else None
 
     if world > 1:
         import torch.distributed as dist
@@ -680,6 +688,7 @@ def main():
                                                "vector peak; dense_equivalent = the reference's 0.53 TFLOP/scan x scans/s, kept for "
                                                "comparison only (the sparse first stage and the restructured conv_1 skip work)"}),
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
+            "second_half_ms_per_step": None if second_half_ms is None else round(second_half_ms, 3),
             "stem_rows_per_launch": None if ctx.get("stem_rows") is None else round(ctx["stem_rows"]),
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
