@@ -756,10 +756,22 @@ _TAP_GEMM_OWN = os.environ.get("SMOS_TAP_GEMM", "mm") == "conv"
 _UPCONV_XY = os.environ.get("SMOS_UPCONV_XY", "1") != "0"
 
 
+def upconv_tap_products(x, wt):
+    """z [B*Hs*Ws, 9*C]: the nine tap products W_t x of a channels-last source map x [B,Cin,Hs,Ws] at its own resolution."""
+    b, cin, hs, ws = x.shape
+    if _TAP_GEMM_OWN and cin % 32 == 0 and (9 * wt.cout) % 128 == 0:
+        return conv_cl(x, wt.conv_operand(), None, 0, 9 * wt.cout, (1, 1), mt=4).permute(0, 2, 3, 1).reshape(b * hs * ws, 9 * wt.cout)
+    rows = x.permute(0, 2, 3, 1).reshape(b * hs * ws, cin)     # no copy for a dense channels-last map
+    # addmm with a zero bias on the [Cin, 9*C] copy of the weights: the library picks a faster kernel for this form than
+    # for mm(rows, nk.t()) (tools/ubench_tapgemm.py: 0.182 vs 0.207 ms at 65536 x 128 x 1152); adding 0 changes no value
+    return torch.addmm(wt.zero, rows, wt.kn)
+
+
 def upconv3x3(conv_a, bias, sources, act, out=None):
     """act(conv_a + bias + sum over sources of conv3x3(bilinear_up(x_src), W_src)) without upsampling (csrc/upconv.hip).
     conv_a: channels-last [B,C,Ho,Wo] view (direct conv of the non-upsampled channels); sources: list of (x_cl
-    [B,Cin,Hs,Ws] channels-last view with dense rows, tap weights from upconv_tap_weights) -- one or two."""
+    [B,Cin,Hs,Ws] channels-last view with dense rows, tap weights from upconv_tap_weights[, tap products from
+    upconv_tap_products: computed here when absent]) -- one or two."""
     _require_cuda("upconv3x3", conv_a, bias, out)
     b, c, ho, wo = conv_a.shape
     if out is None:
@@ -768,21 +780,17 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
     st = _stream(conv_a)
     if not 1 <= len(sources) <= 2:
         raise RuntimeError("upconv3x3: one or two upsampled sources, got %d" % len(sources))
-    fused = _UPCONV_XY and all(lib.smos_upconv_xy_ok(x.shape[2], ho) for x, _ in sources)
+    fused = _UPCONV_XY and all(lib.smos_upconv_xy_ok(src[0].shape[2], ho) for src in sources)
     zs, ts = [], []
     with _on(conv_a.device):
-        for x, wt in sources:
+        for src in sources:
+            x, wt = src[0], src[1]
             hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
             if wt.cin != cin or wt.cout != c:
                 raise RuntimeError("upconv3x3: tap weights are for %d -> %d channels, got %d -> %d" % (wt.cin, wt.cout, cin, c))
-            if _TAP_GEMM_OWN and cin % 32 == 0 and (9 * c) % 128 == 0:
-                z = conv_cl(x, wt.conv_operand(), None, 0, 9 * c, (1, 1), mt=4)
-            else:
-                rows = x.permute(0, 2, 3, 1).reshape(b * hs * ws, cin)     # no copy for a dense channels-last map
-                # [B*Hs*Ws, 9*C]: the nine tap products.  addmm with a zero bias on the [Cin, 9*C] copy of the weights:
-                # the library picks a faster kernel for this form than for mm(rows, nk.t()) (tools/ubench_tapgemm.py:
-                # 0.182 vs 0.207 ms at 65536 x 128 x 1152); adding 0 changes no value
-                z = torch.addmm(wt.zero, rows, wt.kn)
+            z = src[2] if len(src) > 2 and src[2] is not None else upconv_tap_products(x, wt)
+            if tuple(z.shape) != (b * hs * ws, 9 * c) or not z.is_contiguous():
+                raise RuntimeError("upconv3x3: tap products must be a contiguous [B*Hs*Ws, 9*C] matrix, got %s" % (tuple(z.shape),))
             zs.append((z, hs, ws))
             if fused:
                 continue
