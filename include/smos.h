@@ -290,6 +290,17 @@ int smos_conv_wino_cl(const float* x, int64_t x_pitch, const float* wprep, const
                       float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int32_t mb,
                       int32_t act, float* chan_sums, smos_stream_t stream);
 
+/* act(conv(x, w) + bias) for a stride-1 KH x KW kernel with one extent 3 and the other 5 or 7 ("same" padding) in the 1-D
+ * Winograd F(2, 3) form along the 3-tap axis (csrc/conv_wino1d.hip): 4 instead of 6 multiply-adds per pair of outputs, long-
+ * axis tap and channel pair, fp32 throughout.  wprep = U = G g per long-axis tap, computed in float64 and rounded once, in
+ * operand order [cout tile][cin chunk of 16][k-step i][long tap][mb][lane = q * 16 + m][position] (ops.conv_wino1d_prepare);
+ * Cin % 16 == 0, Cout % (16 * mb) == 0, mb in {1, 2}; channels-last maps with row pitches in floats, 16-byte aligned.
+ * Replaces nn.Conv2d + BatchNorm2d + ReLU of the two parallel branches of an Unbalance_BasicBlock
+ * (networks/multi_view_encoder.py:478-497). */
+int smos_conv_wino1d_cl(const float* x, int64_t x_pitch, const float* wprep, const float* bias, float* out, int64_t out_pitch,
+                        int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int32_t mb, int32_t act,
+                        smos_stream_t stream);
+
 /* conv3x3(bilinear_up(x)) without upsampling x (decoder conv_1, multi_view_encoder.py:441-453; csrc/upconv.hip).
  * z [B, Hs, Ws, 9*C] = the nine tap products W_{ky,kx} x at the source resolution (tap t = 3 ky + kx occupies channels
  * [t*C, (t+1)*C)), computed by the caller with one GEMM.

@@ -51,6 +51,7 @@ SIGNATURES = {
     "smos_conv_wino_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
+    "smos_conv_wino1d_cl": [vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_upconv_ypass": [vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_upconv_xy_ok": [i64, i64],

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     const unsigned roff = (c >= 0) ? (unsigned)(((tile / nt_per_sample) / a.T) * a.H * a.W + c) * 4u : kOob;
     r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, roff, 0, 0);      // no row table: zero-sized buffer, reads 0
   };
-  auto cell_resolve = [&](int c, int r) { return (a.row_of != nullptr) & (c >= 0) ? r : c; };
+  auto cell_resolve = [&](int c, int r) { return ((a.row_of != nullptr) & (c >= 0)) ? r : c; };
   int nt = (int)blockIdx.x * (kBlock / kWave) + wave_u;
   TileIn cur, nxt;
   fetch(nt, cur);

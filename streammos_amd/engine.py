@@ -155,6 +155,7 @@ class InferenceEngine:
         self.conv_rows = int(os.environ.get("SMOS_CONV_ROWS", "3"))      # n > 0: row-staging conv for KW >= n at mt = 1; 0: off
         self.fused_gate_sums = os.environ.get("SMOS_GATE_SUMS", "1") != "0"      # ChannelAtt pool sums from the conv epilogue
         self.wino = os.environ.get("SMOS_WINO", "1") != "0"      # Winograd F(2x2,3x3) for the stride-1 3x3 layers (A/B switch)
+        self.wino1d = os.environ.get("SMOS_WINO1D", "1") != "0"  # 1-D Winograd F(2,3) for the k x 3 / 3 x k layers (A/B switch)
         self._wprep = {}
         self._shapes = None
         self._lsi = None
@@ -392,6 +393,14 @@ class InferenceEngine:
             if wp is None:
                 wp = self._wprep[key] = ops.conv_wino_prepare(w, mb)
             return ops.conv_wino_cl(x, wp, bias, act, cout, mb=mb, residual=residual, out=out, chan_sums=chan_sums)
+        if self.wino1d and ops.conv_wino1d_ok((kh, kw), stride, cin, cout, residual, chan_sums):
+            # the k x 3 / 3 x k branches of the Unbalance blocks: 1-D Winograd F(2, 3) along the 3-tap axis (csrc/conv_wino1d.hip)
+            mb = ops.conv_wino_mb(cout)
+            key = (w.data_ptr(), "wino1d", mb)
+            wp = self._wprep.get(key)
+            if wp is None:
+                wp = self._wprep[key] = ops.conv_wino1d_prepare(w, mb)
+            return ops.conv_wino1d_cl(x, wp, bias, act, cout, (kh, kw), mb=mb, out=out)
         mt = ops.conv_mt(cout, b * ho * wo, residual is not None)
         if self.conv_rows and mt <= self.conv_rows_mt and ops.conv_rows_ok((kh, kw), stride, cin, cout) and kw >= self.conv_rows:
             # the row-staging variant (csrc/conv_rows.hip): per layer within 0 .. -5 % of conv_igemm alone on the GPU, +1 % in the

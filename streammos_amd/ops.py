@@ -1054,6 +1054,65 @@ def nhwc_to_nchw(src, dst):
 # channels-last engine kernels: tensors are logical [B, C, H, W] with channels_last strides (possibly a channel
 # slice of a wider channels-last buffer)
 # ---------------------------------------------------------------------------------------------
+_WINO1D_KERNELS = ((5, 3), (7, 3), (3, 5), (3, 7))
+
+
+def conv_wino1d_ok(kernel, stride, cin, cout, residual=None, chan_sums=None):
+    """Shapes smos_conv_wino1d_cl covers: 5x3 / 7x3 / 3x5 / 3x7, stride 1, "same" padding, Cin and Cout multiples of 16, no
+    residual / channel sums (the Unbalance branches have neither)."""
+    return (tuple(kernel) in _WINO1D_KERNELS and stride == 1 and cin % 16 == 0 and cout % 16 == 0 and residual is None and
+            chan_sums is None)
+
+
+def conv_wino1d_prepare(w, mb):
+    """w [Cout, Cin, KH, KW] (BatchNorm folded; one extent 3, the other 5 or 7) -> the weight block of smos_conv_wino1d_cl:
+    U = G g along the 3-tap axis per (cout, cin, long-axis tap) in float64, rounded once to float32, in MFMA operand order
+    [cout tile][cin chunk of 16][k-step i][long tap][mb][lane][position], lane = q * 16 + m holding the four positions of
+    w[ct*16*mb + mb_i*16 + m][chunk*16 + 4*q + i] (include/smos.h)."""
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) not in _WINO1D_KERNELS or cin % 16 or mb not in (1, 2) or cout % (16 * mb):
+        raise RuntimeError("conv_wino1d_prepare: 5x3 / 7x3 / 3x5 / 3x7 kernel, Cin %% 16 == 0 and Cout %% (16 * mb) == 0 required "
+                           "(got %s, mb=%d)" % (tuple(w.shape), mb))
+    g = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    wl = w.double() if kw == 3 else w.double().transpose(2, 3)      # [Cout, Cin, long tap, short tap]
+    kl = wl.shape[2]
+    u = (wl @ g.t()).float()                                        # [Cout, Cin, long tap, position]
+    #          ct               mb_i m   chunk     q  i  kl  pos
+    v = u.reshape(cout // (16 * mb), mb, 16, cin // 16, 4, 4, kl, 4)
+    v = v.permute(0, 3, 5, 6, 1, 4, 2, 7)                           # -> [ct, chunk, i, kl, mb_i, q, m, pos]
+    return v.reshape(-1).contiguous()
+
+
+def conv_wino1d_cl(x, wprep, bias, act, cout, kernel, mb=2, out=None):
+    """act(conv(x) + bias) (stride 1, "same" padding) for a 5x3 / 7x3 / 3x5 / 3x7 kernel on channels-last [B,C,H,W] views in
+    one launch of the 1-D Winograd F(2, 3) kernel (csrc/conv_wino1d.hip).  wprep = conv_wino1d_prepare(w, mb)."""
+    _require_cuda("conv_wino1d_cl", x, wprep, bias, out)
+    b, cin, h, w = x.shape
+    kh, kw = kernel
+    if not conv_wino1d_ok(kernel, 1, cin, cout) or mb not in (1, 2) or cout % (16 * mb) or wprep.numel() != 4 * max(kh, kw) * cout * cin:
+        raise RuntimeError("conv_wino1d_cl: unsupported shape %s -> %d k%dx%d (mb=%d)" % (tuple(x.shape), cout, kh, kw, mb))
+    if out is None:
+        out = empty_cl(b, cout, h, w, x.device)
+    elif tuple(out.shape) != (b, cout, h, w):
+        raise RuntimeError("conv_wino1d_cl: out has shape %s" % (tuple(out.shape),))
+    lib = _lib.load()
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d]" % (b, cin, h, w, cout, h, w, kh, kw)
+    args = (x.data_ptr(), _cl("conv_wino1d_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
+            out.data_ptr(), _cl("conv_wino1d_cl", out), b, h, w, cin, cout, kh, kw, int(mb), int(act))
+    fn = lib.smos_conv_wino1d_cl
+    with _on(x.device), profiling.span(label):
+        rc = fn(*args, _stream(x))
+    _lib.check(rc, "smos_conv_wino1d_cl")
+    if profiling._replay_label == label:
+        keep = (x, wprep, bias, out)
+
+        def again(keep=keep):
+            with _on(keep[0].device), profiling.span(label):
+                _lib.check(fn(*args, _stream(keep[0])), "smos_conv_wino1d_cl")
+        profiling.offer_replay(label, again)
+    return out
+
+
 def empty_cl(b, c, h, w, device, zero=False):
     make = torch.zeros if zero else torch.empty
     return make((b, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)

@@ -926,6 +926,35 @@ def test_conv_wino_cl_is_deterministic_and_batch_independent():
     assert torch.equal(a, b) and torch.equal(a[1:2], c)
 
 
+@pytest.mark.parametrize("cin,cout,hw,kernel,mb,act", [
+    (32, 32, (64, 64), (7, 3), 2, 1), (32, 32, (64, 64), (3, 7), 2, 1), (64, 64, (32, 48), (5, 3), 2, 1), (64, 64, (32, 48), (3, 5), 2, 1),
+    (32, 32, (37, 45), (7, 3), 2, 2), (32, 32, (37, 45), (3, 7), 1, 0), (16, 48, (21, 70), (5, 3), 1, 1), (48, 16, (70, 21), (3, 5), 1, 2),
+    (32, 32, (3, 2), (7, 3), 2, 1), (32, 32, (2, 3), (3, 7), 2, 1), (64, 64, (128, 128), (5, 3), 2, 1), (32, 32, (256, 256), (3, 7), 2, 1)])
+def test_conv_wino1d_cl_against_float64(cin, cout, hw, kernel, mb, act):
+    """The 1-D Winograd F(2, 3) kernel (csrc/conv_wino1d.hip) on the k x 3 / 3 x k shapes of the Unbalance blocks, ragged
+    sizes (items cut by every border, images smaller than a tile) and both orientations, against conv2d in float64; the
+    output may be a channel slice of a wider map (as engine._block_cl writes it).  Bar: 2e-5 of the output range, as for
+    the direct kernels (observed ~3e-7)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    b = 2
+    kh, kw = kernel
+    x = torch.randn((b, cin) + hw, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, kh, kw), generator=gen) / (kh * kw * cin) ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    want = F.conv2d(x.double(), w.double(), bias.double(), 1, (kh // 2, kw // 2))
+    want = want if act == 0 else (torch.relu(want) if act == 1 else F.leaky_relu(want, 0.01))
+    both = ops.empty_cl(b, 2 * cout, hw[0], hw[1], x.device)
+    both.fill_(7.0)
+    got = ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(w, mb), bias, act, cout, kernel, mb=mb, out=both[:, cout:])
+    err = (got.double() - want).abs().max().item() / want.abs().max().item()
+    print("wino1d %d->%d @%s k%dx%d mb %d: %.2e of range" % (cin, cout, hw, kh, kw, mb, err))
+    assert err <= 2e-5
+    assert torch.equal(both[:, :cout], torch.full_like(both[:, :cout], 7.0))          # the neighbouring channels are untouched
+    got2 = ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(w, mb), bias, act, cout, kernel, mb=mb)
+    assert torch.equal(got2, got)                                                     # run-to-run identical, pitch-independent
+
+
 @pytest.mark.parametrize("cin,cout,hw,mb", [(32, 32, (40, 64), 2), (64, 64, (13, 45), 2), (128, 128, (16, 32), 1), (32, 32, (3, 8), 1),
                                             (32, 32, (24, 40), 2)])
 def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb):
