@@ -74,9 +74,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
   const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
   if (iters <= 0) return;
   const int total = iters * a.nchunk;
-#ifdef SMOS_W1D_CLOCK   // diagnostic build only: shader cycles (s_memtime) against the 100 MHz wall clock over the kernel
-  const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
-#endif
 
   auto item_at = [&](int u) {
     Wino1dItem t;
@@ -98,29 +95,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
   const int xp = (int)a.xp;
   const int sc4 = tid & 3, slot = tid >> 2;
   u32x4 st[kPerStep];
+  auto stage_load_one = [&](const Wino1dItem& t, int c, int step, int j, bool valid) {
+    const int p = (step * kPerStep + j) * 64 + slot;
+    const int l = p / 34, s = p - l * 34;
+    const int gl = t.l0 - kPad + l, gs = t.s0 - 1 + s;
+    const bool ok = valid & (p < kRegPix) & ((unsigned)gl < (unsigned)a.nL) & ((unsigned)gs < (unsigned)a.nS);
+    const unsigned off = ok ? (unsigned)(((t.b * a.nL * a.nS + gl * a.sL + gs * a.sS) * xp + 16 * c + 4 * sc4) * 4) : 0x80000000u;
+    st[j] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0);
+  };
+  auto stage_write_one = [&](float* buf, int step, int j) {
+    const int p = (step * kPerStep + j) * 64 + slot;
+    if (p < kRegPix) {
+      float* d = buf + p * kWPP + sc4;        // channel 4 c4 + i of pixel p at word p * 17 + 4 i + c4
+      d[0] = __uint_as_float(st[j].x);
+      d[4] = __uint_as_float(st[j].y);
+      d[8] = __uint_as_float(st[j].z);
+      d[12] = __uint_as_float(st[j].w);
+    }
+  };
   auto stage_load = [&](const Wino1dItem& t, int c, int step, bool valid) {
 #pragma unroll
-    for (int j = 0; j < kPerStep; ++j) {
-      const int p = (step * kPerStep + j) * 64 + slot;
-      const int l = p / 34, s = p - l * 34;
-      const int gl = t.l0 - kPad + l, gs = t.s0 - 1 + s;
-      const bool ok = valid & (p < kRegPix) & ((unsigned)gl < (unsigned)a.nL) & ((unsigned)gs < (unsigned)a.nS);
-      const unsigned off = ok ? (unsigned)(((t.b * a.nL * a.nS + gl * a.sL + gs * a.sS) * xp + 16 * c + 4 * sc4) * 4) : 0x80000000u;
-      st[j] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0);
-    }
+    for (int j = 0; j < kPerStep; ++j) stage_load_one(t, c, step, j, valid);
   };
   auto stage_write = [&](float* buf, int step) {
 #pragma unroll
-    for (int j = 0; j < kPerStep; ++j) {
-      const int p = (step * kPerStep + j) * 64 + slot;
-      if (p < kRegPix) {
-        float* d = buf + p * kWPP + sc4;      // channel 4 c4 + i of pixel p at word p * 17 + 4 i + c4
-        d[0] = __uint_as_float(st[j].x);
-        d[4] = __uint_as_float(st[j].y);
-        d[8] = __uint_as_float(st[j].z);
-        d[12] = __uint_as_float(st[j].w);
-      }
-    }
+    for (int j = 0; j < kPerStep; ++j) stage_write_one(buf, step, j);
   };
 
   // ---- weights: consecutive k-steps' slices are consecutive, cyclically over the block's items (cout tile fastest) ----
@@ -129,14 +128,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   constexpr int kPieces = (kSlot + 255) / 256;   // 1 KB pieces per wave quarter
-  auto w_load = [&](int so) {
+  auto w_piece = [&](int so, int k) {               // piece k of the slice pa_slice names; the last piece advances it
     const float4* s_ = a.w + (int64_t)__builtin_amdgcn_readfirstlane(pa_slice) * kSlot;
+    const int e0 = (k * 4 + wave) * 64;            // this wave's 64 float4 of piece k (wave-uniform)
+    if (e0 < kSlot) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + e0 + lane), (lptr_t)(w_lds + so + e0), 16, 0, 0);
+    if (k == kPieces - 1) pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;
+  };
+  auto w_load = [&](int so) {
 #pragma unroll
-    for (int k = 0; k < kPieces; ++k) {
-      const int e0 = (k * 4 + wave) * 64;        // this wave's 64 float4 of piece k (wave-uniform)
-      if (e0 < kSlot) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + e0 + lane), (lptr_t)(w_lds + so + e0), 16, 0, 0);
-    }
-    pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;
+    for (int k = 0; k < kPieces; ++k) w_piece(so, k);
   };
 
   f32x4 acc[4][MB][4];
@@ -173,29 +173,48 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
 
   // ---- one k-step: the wave's 4 + KL - 1 input rows in turn.  The fragments of this k-step are in af on entry; so1: the next
   //      k-step's slice, from which af is refilled tap by tap.  The pixels of row li + 1 are requested before the MFMAs of row
-  //      li and transformed behind them: the LDS latency lies under 8 * MB * (rows reached) matrix instructions. ----
-  auto kstep = [&](const float* buf, int i, int so1) {
-    float v[2][4];
+  //      li and transformed behind them.  With one wave per SIMD nothing but the wave's own instruction stream can fill the
+  //      matrix pipe's shadow, so everything else a k-step has to do rides INSIDE the MFMA stream, one piece behind the first
+  //      eight MFMAs of an input row: the weight DMA of k-step + 2 (rows 0 ..), the requests for a quarter of the next chunk's
+  //      region (three rows in the middle) and its stores (the last three rows, three rows = ~3000 cycles behind the request). ----
+  constexpr int kLi = 4 + KL - 1;
+  auto kstep = [&](const float* buf, float* nbuf, int i, int so1, int so2, const Wino1dItem& nt, int nc, bool more) {
+    float v[3][4];                              // row li's B operands, row li + 1 (transformed during li), row li + 2 (in flight)
     load_patch(buf, 0, i, v[0]);
+    load_patch(buf, 1, i, v[1]);
+    transform(v[0]);
+    SMOS_FENCE();
 #pragma unroll
-    for (int li = 0; li < 4 + KL - 1; ++li) {
-      transform(v[li & 1]);
-      if (li + 1 < 4 + KL - 1) load_patch(buf, li + 1, i, v[(li + 1) & 1]);
-      SMOS_FENCE();
+    for (int li = 0; li < kLi; ++li) {
+      int n_mfma = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = li - r;
         if (kl < 0 || kl >= KL) continue;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          acc[r][mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].x, v[li & 1][0], acc[r][mb][0], 0, 0, 0);
-          acc[r][mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].y, v[li & 1][1], acc[r][mb][1], 0, 0, 0);
-          acc[r][mb][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].z, v[li & 1][2], acc[r][mb][2], 0, 0, 0);
-          acc[r][mb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].w, v[li & 1][3], acc[r][mb][3], 0, 0, 0);
+          acc[r][mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].x, v[li % 3][0], acc[r][mb][0], 0, 0, 0);
+          acc[r][mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].y, v[li % 3][1], acc[r][mb][1], 0, 0, 0);
+          acc[r][mb][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].z, v[li % 3][2], acc[r][mb][2], 0, 0, 0);
+          acc[r][mb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kl][mb].w, v[li % 3][3], acc[r][mb][3], 0, 0, 0);
+        }
+        n_mfma += 4 * MB;
+      }
+      // everything else of this row: independent of its MFMAs, to be issued one instruction per MFMA shadow
+      if (li + 1 < kLi) transform(v[(li + 1) % 3]);
+      if (li + 2 < kLi) load_patch(buf, li + 2, i, v[(li + 2) % 3]);
+      if (li < kPieces) w_piece(so2, li);
+      if (li >= kLi - 6 && li < kLi - 3) stage_load_one(nt, nc, i, li - (kLi - 6), more);
+      if (li >= kLi - 3) stage_write_one(nbuf, i, li - (kLi - 3));
+      if (li >= 3) a_read(so1, li - 3);        // tap li - 3 has served its last output row: next k-step's fragment
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        if (k < n_mfma) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x096, 1, 0);     // one VALU / SALU / VMEM / DS instruction
         }
       }
       SMOS_FENCE();
-      if (li >= 3) a_read(so1, li - 3);        // tap li - 3 has served its last output row: next k-step's fragment
     }
   };
 
@@ -268,13 +287,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
     const Wino1dItem nxt = item_at(first + (more ? it1 : it));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // requested at the head, needed behind the k-step's 28 * KL / 7 * 8 MFMAs (~3 us): the slice of k-step + 2 (this
-      // k-step refills the fragments from the slice of k-step + 1, complete since the previous barrier) and a quarter of the
-      // next chunk's region, stored at the tail.  hipcc does not count LDS-DMA against LDS reads: explicit wait, then barrier.
-      w_load(so2);
-      stage_load(nxt, c1, i, more);
-      kstep(buf_cur, i, so1);
-      stage_write(buf_nxt, i);
+      // inside the k-step: the slice of k-step + 2 (this k-step refills the fragments from the slice of k-step + 1, complete
+      // since the previous barrier) and a quarter of the next chunk's region.  hipcc does not count LDS-DMA against LDS reads:
+      // explicit wait, then barrier.
+      kstep(buf_cur, buf_nxt, i, so1, so2, nxt, c1, more);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ring_barrier();
       const int r_ = so0;
@@ -289,13 +305,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
     buf_cur = buf_nxt;
     buf_nxt = sw;
   }
-#ifdef SMOS_W1D_CLOCK
-  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) {
-    const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dw = wall_clock64() - dbg_w0;
-    printf("block %d: %llu shader cycles in %llu ticks of 10 ns = %.3f GHz; %d k-steps: %.0f cycles each\n", (int)blockIdx.x, dc, dw,
-           (double)dc / (10.0 * (double)dw), total * 4, (double)dc / (total * 4));
-  }
-#endif
 }
 
 }  // namespace smos
