@@ -162,10 +162,14 @@ def event_bracket_overhead(device, n=64):
 
 def executed_launch_flops(label, wino=True):
     """FLOPs one labelled launch issues on the matrix cores: the algorithmic count, except that a stride-1 3x3 convolution
-    in the Winograd F(2x2, 3x3) form issues 4 instead of 9 multiply-adds per output and channel pair."""
+    in the Winograd F(2x2, 3x3) form issues 4 instead of 9 multiply-adds per output and channel pair, a k x 3 / 3 x k one in the
+    1-D F(2, 3) form two thirds of the direct count."""
     fl = algorithmic_flops(label)
     if fl and wino and label.startswith("conv_cl["):
         geo = _conv_geometry(label.split("[", 1)[1].rstrip("]"))
+        if geo["ho"] == geo["h"] and geo["wo"] == geo["w"] and geo["cin"] % 16 == 0 and geo["cout"] % 16 == 0 and "+res" not in label[-6:]:
+            if (geo["kh"], geo["kw"]) in ((5, 3), (7, 3), (3, 5), (3, 7)):
+                return fl * 2 // 3              # 1-D F(2, 3) along the 3-tap axis
         if (geo["kh"], geo["kw"]) == (3, 3) and geo["ho"] == geo["h"] and geo["wo"] == geo["w"] and geo["cin"] % 16 == 0 and geo["cout"] % 16 == 0:
             return fl * 4 // 9
     return fl
@@ -186,8 +190,12 @@ def executed_flops(engine, b, n, t, stem_class_rows):
     def conv(w, px, stride=1):
         # stride-1 3x3 layers run in the Winograd F(2x2, 3x3) form (csrc/conv_wino.hip): 16 multiply-adds per 2x2 outputs and
         # channel pair = 4 per output instead of 9 (the transforms are additions on the vector unit and are not counted)
-        taps = 4 if (wino and stride == 1 and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0) \
-            else w.shape[2] * w.shape[3]
+        taps = w.shape[2] * w.shape[3]
+        if stride == 1 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+            if wino and tuple(w.shape[2:]) == (3, 3):
+                taps = 4
+            elif getattr(engine, "wino1d", False) and tuple(w.shape[2:]) in ((5, 3), (7, 3), (3, 5), (3, 7)):
+                taps = taps * 2 // 3            # 1-D F(2, 3) along the 3-tap axis (csrc/conv_wino1d.hip): 4 instead of 6 per output pair
         return 2.0 * b * px * w.shape[0] * w.shape[1] * taps
 
     def stage(blocks, h, w, first_sparse=False):
