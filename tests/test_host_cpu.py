@@ -438,3 +438,56 @@ def test_conv_wino_prepare_operand_order_reproduces_the_convolution():
         ops.conv_wino_prepare(torch.zeros(32, 32, 5, 3), 2)          # not a 3x3 kernel
     with pytest.raises(RuntimeError):
         ops.conv_wino_prepare(torch.zeros(16, 32, 3, 3), 2)          # Cout not a multiple of 16 * mb
+
+
+def test_conv_wino1d_prepare_operand_order_reproduces_the_convolution():
+    """Host logic of the 1-D Winograd path without a GPU: ops.conv_wino1d_prepare packs U = G g (per long-axis tap) in the
+    operand order include/smos.h documents; unpacking with the documented index formula and running F(2, 3) along the 3-tap
+    axis in numpy (B^T d, sums over channels and long-axis taps, A^T m) must give conv2d -- for both orientations."""
+    import torch.nn.functional as F
+    from streammos_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    g = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]])
+    bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    at = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    for cin, cout, mb, (kh, kw) in ((16, 16, 1, (5, 3)), (32, 32, 2, (7, 3)), (16, 32, 2, (3, 5)), (32, 16, 1, (3, 7))):
+        w = torch.randn((cout, cin, kh, kw), generator=gen, dtype=torch.float32)
+        kl = max(kh, kw)
+        packed = ops.conv_wino1d_prepare(w, mb).numpy()
+        assert packed.size == 4 * kl * cout * cin
+        # wprep[((((ct * (Cin/16) + cc) * 4 + i) * KL + kL) * mb + m) * 64 + lane][pos] = U[kL][pos] of
+        # w[ct*16*mb + m*16 + (lane & 15)][cc*16 + 4*(lane >> 4) + i]
+        blk = packed.reshape(cout // (16 * mb), cin // 16, 4, kl, mb, 64, 4)
+        u = np.zeros((cout, cin, kl, 4), dtype=np.float64)
+        for lane in range(64):
+            for i in range(4):
+                for ct in range(cout // (16 * mb)):
+                    for m in range(mb):
+                        co = ct * 16 * mb + m * 16 + (lane & 15)
+                        for cc in range(cin // 16):
+                            u[co, cc * 16 + 4 * (lane >> 4) + i] = blk[ct, cc, i, :, m, lane, :]
+        wl = w.numpy().astype(np.float64) if kw == 3 else w.numpy().astype(np.float64).transpose(0, 1, 3, 2)     # [co, ci, long, short]
+        want_u = np.einsum("pk,oclk->oclp", g, wl)
+        assert np.abs(u - want_u).max() <= 1e-6 * np.abs(want_u).max()
+        x = torch.randn((2, cin, 6, 8), generator=gen)
+        want = F.conv2d(x.double(), w.double(), None, 1, (kh // 2, kw // 2)).numpy()
+        xl = x.numpy().astype(np.float64) if kw == 3 else x.numpy().astype(np.float64).transpose(0, 1, 3, 2)     # [b, c, L, S]
+        n_l, n_s = xl.shape[2], xl.shape[3]
+        xp = np.pad(xl, ((0, 0), (0, 0), (kl // 2, kl // 2), (1, 1 + n_s % 2)))
+        out = np.zeros((2, cout, n_l, n_s + n_s % 2))
+        for l in range(n_l):
+            for t in range((n_s + 1) // 2):
+                m_acc = np.zeros((2, cout, 4))
+                for k in range(kl):
+                    v = np.einsum("pj,bcj->bcp", bt, xp[:, :, l + k, 2 * t:2 * t + 4])
+                    m_acc += np.einsum("ocp,bcp->bop", u[:, :, k, :], v)
+                out[:, :, l, 2 * t:2 * t + 2] = np.einsum("ep,bop->boe", at, m_acc)
+        out = out[:, :, :, :n_s]
+        out = out if kw == 3 else out.transpose(0, 1, 3, 2)
+        assert np.abs(out - want).max() <= 1e-5 * np.abs(want).max(), (cin, cout, mb, kh, kw)
+    with pytest.raises(RuntimeError):
+        ops.conv_wino1d_prepare(torch.zeros(32, 32, 3, 3), 2)        # 3x3 is the 2-D kernel's
+    with pytest.raises(RuntimeError):
+        ops.conv_wino1d_prepare(torch.zeros(16, 32, 7, 3), 2)        # Cout not a multiple of 16 * mb
+    assert ops.conv_wino1d_ok((7, 3), 1, 32, 32) and not ops.conv_wino1d_ok((7, 3), 2, 32, 32)
+    assert not ops.conv_wino1d_ok((7, 3), 1, 32, 32, residual=object()) and not ops.conv_wino1d_ok((7, 7), 1, 32, 32)
