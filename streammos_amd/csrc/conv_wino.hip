@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // ---- weights: the slices of consecutive k-steps are consecutive, cyclically over the block's items (cout tile fastest).
   // They travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write; a wave's 64 lanes fill 1 KB
   // of the slot, which is exactly the slice's lane-linear layout): the slice of k-step s + 2 is requested at the head of
-  // k-step s into ring slot (s + 2) % 3.  hipcc does not count LDS-DMA against LDS reads, so the wait is explicit: before the
+  // k-step s into ring slot (s + 2) % 3.  hipcc's own ordering of LDS-DMA against LDS reads is not what the ring needs (it puts
+  // s_waitcnt vmcnt(0) in front of the first LDS read that may alias a pending DMA, once per k-step; another wave's DMA it cannot
+  // see at all), so the wait that matters is explicit: before the
   // barrier that ends k-step s, everything but the requests issued during k-step s itself has landed (vmcnt retires in
   // order), i.e. the slice k-step s + 1 reads ----
   const int n_slices = a.nct * a.nchunk * 4;

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino1d(Wino1dArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // inside the k-step: the slice of k-step + 2 (this k-step refills the fragments from the slice of k-step + 1, complete
-      // since the previous barrier) and a quarter of the next chunk's region.  hipcc does not count LDS-DMA against LDS reads:
+      // since the previous barrier) and a quarter of the next chunk's region.  a wave's wait counter knows nothing of the other waves' DMA:
       // explicit wait, then barrier.
       kstep(buf_cur, buf_nxt, i, so1, so2, nxt, c1, more);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
