@@ -382,7 +382,7 @@ def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4):
         dt = time.perf_counter() - t0
         return {"value": round(batch * steps / dt, 3), "unit": "samples/s (one GPU; a sample = 3 chained forwards + backward)",
                 "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "batch_per_gpu": batch, "frame_point_num": frame_point_num,
-                "loss": round(float(loss), 5), "batchnorm_layers": n_bn, "trainable_tensors": len(trainable),
+                "loss": round(float(loss.detach()), 5), "batchnorm_layers": n_bn, "trainable_tensors": len(trainable),
                 "collectives_per_step_at_2_or_more_ranks": dict({k: v // steps for k, v in sorted(counts.items())},
                                                                 ddp_gradient_bucket_all_reduce=1, ddp_used_parameter_bitmap_all_reduce=1,
                                                                 loss_reduce_to_rank0=1),

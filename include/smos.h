@@ -7,7 +7,8 @@
  *     vectors unless the comment says "device",
  *   - launches asynchronously on the hipStream_t passed as `stream` (never on the legacy default
  *     stream, unlike the reference's deep_point launches, point_deep_cuda_kernel.cu:153-160),
- *   - allocates nothing, synchronises nothing, keeps no global state (graph-capturable),
+ *   - allocates nothing, synchronises nothing, keeps no global state (graph-capturable; the one exception is the test
+ *     hook smos_debug_set_conv_grid_cap below),
  *   - returns SMOS_OK or an error code; smos_last_error() gives the thread-local message that the
  *     Python shims turn into RuntimeError (the reference raises c10::Error -> RuntimeError,
  *     point_deep_cuda.cpp:11-13).
@@ -38,6 +39,10 @@ typedef void* smos_stream_t; /* hipStream_t */
 
 int smos_abi_version(void);
 const char* smos_last_error(void);
+/* Test hook (process-wide, not part of the data path; the one piece of state the library keeps): caps the grid of the
+ * persistent convolution kernels (smos_conv_cl / _rows_cl / _wino_cl / _wino1d_cl) at `blocks`, 0 = no cap.  It makes one
+ * block walk several work items -- the item-boundary code paths -- on shapes small enough to check against float64. */
+int smos_debug_set_conv_grid_cap(int32_t blocks);
 
 /* --------------------------------------------------------------------------------------------
  * Point -> grid max-pool scatter.

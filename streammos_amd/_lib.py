@@ -19,6 +19,7 @@ i32 = ctypes.c_int32
 # name -> argtypes, in the order of include/smos.h
 SIGNATURES = {
     "smos_abi_version": [],
+    "smos_debug_set_conv_grid_cap": [i32],
     "smos_voxel_maxpool_fwd": [vp, c_i64p, vp, vp, c_i64p, vp, i64, i64, i64, i32, c_i64p, c_f32p, i32, vp, vp],
     "smos_voxel_maxpool_bwd": [vp, c_i64p, vp, vp, vp, c_i64p, vp, i64, i64, i64, i32, c_i64p, c_f32p, i32, vp],
     "smos_bilinear_gather_fwd": [vp, c_i64p, vp, i32, vp, c_i64p, i64, i64, i64, i64, i64, c_f32p, vp],

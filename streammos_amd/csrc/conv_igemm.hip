@@ -395,7 +395,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return v[MT == 1 ? 0 : MT == 2 ? 1 : 2];
   }();
   const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
-  const int64_t cap = (int64_t)ks.cus * per_cu;
+  const int64_t cap = conv_grid_cap((int64_t)ks.cus * per_cu);
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_igemm<MT, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_cl");

@@ -337,7 +337,7 @@ static int launch_rows(const ConvArgs& a, hipStream_t s) {
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_rows<KW, MT, RES, SUMS>), 4 * 256 * MT * sizeof(float4) + 8192 + rows, 256, &ks, "conv_rows_cl"))
     return rc;
   const int per_cu = ks.per_cu < 2 ? ks.per_cu : 2;
-  const int64_t cap = (int64_t)ks.cus * per_cu;
+  const int64_t cap = conv_grid_cap((int64_t)ks.cus * per_cu);
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_rows<KW, MT, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_rows_cl");

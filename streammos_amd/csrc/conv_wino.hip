@@ -416,9 +416,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
                  WINO_STAGE_WRITE_A(buf_nxt); WINO_W_LOAD(so2); WINO_STAGE_LOAD_B(nxt, c1, g + 1 < total), MB + 3);
       WINO_KSTEP(vb, va, buf_cur, 2, WINO_W_LOAD(so2), (void)0, MB + 3);
       WINO_KSTEP(va, vb, buf_cur, 3, (void)0, WINO_STAGE_WRITE_B(buf_nxt); WINO_W_LOAD(so2), MB);
-      // (when an item ends with this chunk, the request goes out behind the epilogue instead of across it)
-      WINO_KSTEP(vb, va, buf_nxt, 0, WINO_W_LOAD(so2); if (c1 != 0) WINO_STAGE_LOAD_A(nn, c2, g + 2 < total), (void)0, MB + 3);
-      if (c1 == 0) {
+      // (when an item ends with this chunk, the region request goes out behind the epilogue instead of across it; the k-step's
+      // HEAD then issues the weight DMA only, so its barrier may leave MB requests in flight, not MB + 3 -- with MB + 3 the
+      // slice the next k-step reads could still be on its way)
+      if (c1 != 0) {
+        WINO_KSTEP(vb, va, buf_nxt, 0, WINO_W_LOAD(so2); WINO_STAGE_LOAD_A(nn, c2, g + 2 < total), (void)0, MB + 3);
+      } else {
+        WINO_KSTEP(vb, va, buf_nxt, 0, WINO_W_LOAD(so2), (void)0, MB);
         epilogue(cur);
         cur = nxt;
         WINO_STAGE_LOAD_A(nn, c2, g + 2 < total);
@@ -467,7 +471,7 @@ static int launch_wino(const WinoArgs& a, hipStream_t s) {
     return v;
   }();
   const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
-  const int64_t cap = (int64_t)ks.cus * per_cu;
+  const int64_t cap = conv_grid_cap((int64_t)ks.cus * per_cu);
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_wino<MB, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_wino_cl");

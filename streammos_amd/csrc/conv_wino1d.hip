@@ -316,7 +316,7 @@ static int launch_wino1d(const Wino1dArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (16 + KL - 1) * 34 * kWPP * sizeof(float) + (size_t)3 * KL * MB * 64 * sizeof(float4);
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&conv_wino1d<KL, MB>), lds, 256, &ks, "conv_wino1d_cl")) return rc;
-  const int64_t cap = (int64_t)ks.cus;          // one block per CU: the region and the ring take 145 KB of LDS at K = 7
+  const int64_t cap = conv_grid_cap((int64_t)ks.cus);          // one block per CU: the region and the ring take 145 KB of LDS at K = 7
   const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
   hipLaunchKernelGGL((conv_wino1d<KL, MB>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_wino1d_cl");

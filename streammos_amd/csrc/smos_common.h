@@ -52,6 +52,10 @@ struct KernelSetup {
 };
 int kernel_setup(const void* fn, size_t dyn_lds_bytes, int occupancy_block, KernelSetup* out, const char* what);
 
+// smos_debug_set_conv_grid_cap: upper bound on the grid of the persistent convolution kernels (0 = none).  A test hook: it makes
+// a block walk several work items on shapes small enough to check against float64, on any CU count.
+int64_t conv_grid_cap(int64_t cap);
+
 // One row of the 4x4 pose difference times (x, y, z, 1) in float64, in the operation order of the dgemm micro-kernel
 // numpy's ``mat.dot`` runs for datasets/utils.py:116-126 (one accumulator per output element, k = 0..3, fused
 // multiply-adds): written with the round-to-nearest intrinsics so that -ffp-contract has nothing to decide.  The result

@@ -1,6 +1,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -50,7 +51,16 @@ int kernel_setup(const void* fn, size_t dyn_lds_bytes, int occupancy_block, Kern
   *out = it->second;
   return SMOS_OK;
 }
+static std::atomic<int> g_conv_grid_cap{0};
+int64_t conv_grid_cap(int64_t cap) {
+  const int lim = g_conv_grid_cap.load(std::memory_order_relaxed);
+  return lim > 0 && lim < cap ? lim : cap;
+}
 }  // namespace smos
 
+extern "C" int smos_debug_set_conv_grid_cap(int32_t blocks) {
+  smos::g_conv_grid_cap.store(blocks > 0 ? blocks : 0, std::memory_order_relaxed);
+  return SMOS_OK;
+}
 extern "C" int smos_abi_version(void) { return SMOS_ABI_VERSION; }
 extern "C" const char* smos_last_error(void) { return smos::g_err; }

@@ -254,7 +254,7 @@ class InferenceEngine:
         race in each case."""
         table = p.__dict__.get("ws")
         if table is None:
-            table = p.__dict__["ws"] = ops.new_block_scratch()     # registered: release_stream_workspaces purges it
+            table = p.__dict__["ws"] = ops.new_block_scratch(self.device)     # registered: release_stream_workspaces purges it
         key = (torch.cuda.current_stream(self.device).cuda_stream, ops._ws_namespace)
         ws = table.get(key)
         if ws is None or ws.numel() < n_floats:

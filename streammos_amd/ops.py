@@ -25,10 +25,25 @@ def set_workspace_namespace(tag):
     return prev
 
 
+# The two private torch._C entry points behind torch.cuda.current_stream(...).cuda_stream / torch.cuda.current_device(),
+# resolved once; a torch build without them gets the public (slower: ~4 us + ~3 us per launch) calls instead.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+if _raw_stream is None:
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+if _raw_device is None:
+    _raw_device = torch.cuda.current_device
+
+
+def _dev_index(device):
+    return device.index if device.index is not None else _raw_device()
+
+
 def _stream(t):
     """raw handle of torch's current HIP stream on t's device (the C call behind torch.cuda.current_stream(...).cuda_stream:
     the wrapper objects cost ~4 us per launch on the host)."""
-    return torch._C._cuda_getCurrentRawStream(t.device.index)
+    return _raw_stream(_dev_index(t.device))
 
 
 class _NoGuard:
@@ -48,7 +63,7 @@ _NO_GUARD = _NoGuard()
 def _on(device):
     """Device guard for a launch: torch.cuda.device(...) only where the tensor's device is not the current one (the usual
     one-process-per-GPU case never switches; the guard object and its two device queries cost ~3 us per launch)."""
-    return _NO_GUARD if torch._C._cuda_getDevice() == device.index else torch.cuda.device(device)
+    return _NO_GUARD if device.index is None or _raw_device() == device.index else torch.cuda.device(device)
 
 
 def _require_cuda(name, *tensors):
@@ -854,7 +869,7 @@ def _stream_workspace(tag, shape, dtype, device, zero=False):
 class BlockScratch(dict):
     """{(HIP stream, namespace): buffer} of one ChannelAtt block (engine._block_ws); a dict that can be weakly referenced,
     so the registry below does not keep a dead engine's scratch alive."""
-    __slots__ = ("__weakref__",)
+    __slots__ = ("__weakref__", "device")
     __hash__ = object.__hash__            # identity: the registry is a WeakSet
     __eq__ = object.__eq__
 
@@ -871,8 +886,9 @@ def new_workspace_owner():
     return next(_owner_tokens)
 
 
-def new_block_scratch():
+def new_block_scratch(device=None):
     table = BlockScratch()
+    table.device = None if device is None else str(device)
     _block_ws_tables.add(table)
     return table
 
@@ -883,24 +899,27 @@ def release_stream_workspaces(device=None, stream=None, owner=None):
     scatter's flag words and the channel-attention blocks' plane sums alike.  StreamRunner.close() calls this."""
     def owned(ns):
         return isinstance(ns, tuple) and len(ns) > 1 and ns[1] == owner
-    for key in list(_stem_ws):
+
+    def graph_ns(ns):
+        # scratch baked into some runner's captured graphs: only that runner (the owner path) may drop it -- torch hands
+        # pooled streams to several runners, so a stream handle alone does not say whose scratch an entry is
+        return isinstance(ns, tuple) and len(ns) > 1 and ns[0] == "graph"
+
+    def selected(dev, st, ns):
         if owner is not None:
-            if owned(key[4]):
-                del _stem_ws[key]
-        elif (device is None or key[0] == str(device)) and (stream is None or key[1] == stream):
+            return owned(ns)
+        if (device is not None or stream is not None) and graph_ns(ns):
+            return False
+        return (device is None or dev is None or dev == str(device)) and (stream is None or st == stream)
+    for key in list(_stem_ws):                       # (device, stream, tag, dtype, namespace)
+        if selected(key[0], key[1], key[4]):
             del _stem_ws[key]
     for key in list(_flag_ws):                       # (device, stream, namespace)
-        if owner is not None:
-            if owned(key[2]):
-                del _flag_ws[key]
-        elif (device is None or str(key[0]) == str(device)) and (stream is None or key[1] == stream):
+        if selected(str(key[0]), key[1], key[2]):
             del _flag_ws[key]
     for table in list(_block_ws_tables):             # engine._block_ws: {(stream, namespace): buffer} per ChannelAtt block
         for key in list(table):
-            if owner is not None:
-                if owned(key[1]):
-                    del table[key]
-            elif stream is None or key[0] == stream:
+            if selected(table.device, key[0], key[1]):
                 del table[key]
 
 

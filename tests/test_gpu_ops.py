@@ -955,6 +955,94 @@ def test_conv_wino1d_cl_against_float64(cin, cout, hw, kernel, mb, act):
     assert torch.equal(got2, got)                                                     # run-to-run identical, pitch-independent
 
 
+@pytest.fixture
+def conv_grid_cap():
+    """smos_debug_set_conv_grid_cap for the duration of a test: the persistent conv kernels launch at most `blocks` blocks, so a
+    block walks several work items on shapes that are still small enough for a float64 reference."""
+    from streammos_amd import _lib
+    lib = _lib.load()
+
+    def set_cap(blocks):
+        _lib.check(lib.smos_debug_set_conv_grid_cap(int(blocks)), "smos_debug_set_conv_grid_cap")
+    yield set_cap
+    lib.smos_debug_set_conv_grid_cap(0)
+
+
+_WINO_WALK_CASES = [
+    # cin, cout, (h, w), mb, act, residual, batch, grid cap (0 = the device's own resident grid)
+    (64, 64, (256, 256), 2, 1, False, 4, 0),        # VERDICT r3: 2048 items on 512 resident blocks (conv_2-like walk at full grid)
+    (64, 64, (40, 96), 2, 2, True, 3, 7),           # 5 x 3 x 2 x 3 = 90 items on 7 blocks: 13 per block, nct = 2, x / y / sample wraps inside a block
+    (32, 96, (24, 64), 2, 1, False, 2, 5),          # nct = 3 (odd): blocks start at every cout tile; weight-slice counter wraps mid-block
+    (48, 32, (17, 70), 1, 0, True, 2, 4),           # mb = 1 (the early-request schedule), 3 chunks, ragged edges, 54 items on 4 blocks
+    (16, 32, (16, 64), 1, 1, False, 3, 3),          # one chunk per item: every k-step group ends an item (mb = 1: epilogue before the region request)
+    (16, 32, (16, 64), 2, 1, True, 3, 3),           # the same at mb = 2
+]
+
+
+@pytest.mark.parametrize("cin,cout,hw,mb,act,with_res,b,cap", _WINO_WALK_CASES)
+def test_conv_wino_cl_persistent_walk_over_several_items(cin, cout, hw, mb, act, with_res, b, cap, conv_grid_cap):
+    """The persistent multi-item walk of csrc/conv_wino.hip (next_item, the region prefetch across an item boundary, the
+    epilogue between items, the cyclic weight-slice counter, conv_wino.hip:72-82,178-191,404-447): shapes with MORE work items
+    than blocks, with the cout-tile / x / y / sample wraps all inside one block -- against conv2d in float64 (2e-5 of the range)
+    and against the direct kernel (4e-6), whose walk is independent of this one.  Layers: networks/backbone.py:136-159,
+    networks/multi_view_encoder.py:478-497."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(101)
+    h, w = hw
+    x = torch.randn((b, h, w, cin), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    res = torch.randn((b, h, w, cout), generator=gen).to(DEV).permute(0, 3, 1, 2) if with_res else None
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (cin * 9)) ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    items = b * ((h + 7) // 8) * ((w + 31) // 32) * (cout // (16 * mb))
+    conv_grid_cap(cap)
+    got = ops.conv_wino_cl(x, ops.conv_wino_prepare(wt, mb), bias, act, cout, mb=mb, residual=res)
+    conv_grid_cap(0)
+    want = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)
+    if with_res:
+        want = want + res.double()
+    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.01) if act == 2 else want)
+    scale = want.abs().max().item()
+    err = (got.double() - want).abs().max().item() / scale
+    print("wino walk %d->%d @%s mb %d: %d items, cap %d: %.2e of range" % (cin, cout, hw, mb, items, cap, err))
+    assert err <= 2e-5, err
+    if cin % 32 == 0 and cout % 32 == 0:
+        direct = ops.conv_cl(x, ops.conv_prepare(wt, 1), bias, act, cout, (3, 3), mt=1, residual=res)
+        assert (got - direct).abs().max().item() <= 4e-6 * scale
+    # the uncapped launch of the same layer is the same function: bit-identical (what the engine relies on across devices)
+    again = ops.conv_wino_cl(x, ops.conv_wino_prepare(wt, mb), bias, act, cout, mb=mb, residual=res)
+    assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("cin,cout,hw,kernel,mb,act,b,cap", [
+    (64, 64, (256, 256), (5, 3), 2, 1, 3, 0),       # 768 items on 256 resident blocks, nct = 2
+    (32, 32, (256, 256), (3, 7), 2, 1, 4, 0),       # 512 items, nct = 1, the x-long orientation
+    (32, 64, (50, 70), (7, 3), 2, 2, 2, 5),         # 4 x 3 x 2 x 2 = 48 items on 5 blocks: every wrap inside a block, ragged
+    (48, 48, (70, 50), (3, 5), 1, 0, 2, 4),         # mb = 1, nct = 3, 3 chunks
+    (16, 32, (33, 64), (5, 3), 2, 1, 2, 3),         # one chunk per item
+])
+def test_conv_wino1d_cl_persistent_walk_over_several_items(cin, cout, hw, kernel, mb, act, b, cap, conv_grid_cap):
+    """The same for csrc/conv_wino1d.hip (one block per CU; 16 L-rows x 32 S-columns x 16 mb couts per item)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(103)
+    kh, kw = kernel
+    x = torch.randn((b, cin) + hw, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, kh, kw), generator=gen) / (kh * kw * cin) ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    conv_grid_cap(cap)
+    got = ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(w, mb), bias, act, cout, kernel, mb=mb)
+    conv_grid_cap(0)
+    want = F.conv2d(x.double(), w.double(), bias.double(), 1, (kh // 2, kw // 2))
+    want = want if act == 0 else (torch.relu(want) if act == 1 else F.leaky_relu(want, 0.01))
+    scale = want.abs().max().item()
+    err = (got.double() - want).abs().max().item() / scale
+    print("wino1d walk %d->%d @%s k%dx%d mb %d cap %d: %.2e of range" % (cin, cout, hw, kh, kw, mb, cap, err))
+    assert err <= 2e-5
+    if cin % 32 == 0 and cout % 32 == 0:
+        direct = ops.conv_cl(x, ops.conv_prepare(w, 1), bias, act, cout, kernel, mt=1)
+        assert (got - direct).abs().max().item() <= 4e-6 * scale
+    assert torch.equal(ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(w, mb), bias, act, cout, kernel, mb=mb), got)
+
+
 @pytest.mark.parametrize("cin,cout,hw,mb", [(32, 32, (40, 64), 2), (64, 64, (13, 45), 2), (128, 128, (16, 32), 1), (32, 32, (3, 8), 1),
                                             (32, 32, (24, 40), 2)])
 def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb):

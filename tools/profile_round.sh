@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-raw > $OUT/bench_trace.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --train-steps 0 --no-raw > $OUT/bench_trace.log 2>&1
 echo "trace done"
 # the same with the two pipeline streams folded into one: per-kernel durations without the other stream's kernels on the CUs
 # (whether the tracer serialises the two streams by itself differs from box to box)
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --no-raw --no-pipeline --label-log $OUT/labels_serial.json > $OUT/bench_trace_serial.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o t --output-format csv -- python3 -u $R/bench.py --steps 20 --warmup 6 --cpu-scans 0 --train-steps 0 --no-raw --no-pipeline --label-log $OUT/labels_serial.json > $OUT/bench_trace_serial.log 2>&1
 echo "serial trace done"
-PMCARGS="--steps 3 --warmup 2 --frames 3 --cpu-scans 0 --no-raw --no-pipeline"
+PMCARGS="--steps 3 --warmup 2 --frames 3 --cpu-scans 0 --train-steps 0 --no-raw --no-pipeline"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 -u $R/bench.py $PMCARGS --label-log $OUT/labels.json > $OUT/bench_fetch.log 2>&1
 echo "fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 -u $R/bench.py $PMCARGS > $OUT/bench_write.log 2>&1
