@@ -133,6 +133,14 @@ def algorithmic_flops(label, ctx=None):
     if name == "conv_cl":
         geo = _conv_geometry(dims)
         return 2 * geo["b"] * geo["ho"] * geo["wo"] * geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"]
+    if name == "stem_gemm":
+        # sparse DownSample2D 192 -> 32 on the occupied cells: a cell of parity class c feeds STEM_TAPS[c] conv taps plus the
+        # 1x1 pool branch (csrc/stem.hip).  Needs the frames' occupancy; without it the launch is priced by its bytes only.
+        b, h, w, cin = (int(v) for v in dims.split("x"))
+        rows = (ctx or {}).get("stem_class_rows")
+        if rows is None:
+            return 0
+        return int(sum(2.0 * r * cin * 32 * (taps + 1) for r, taps in zip(rows, (1, 2, 2, 4))))
     return 0
 
 
@@ -168,11 +176,14 @@ def calibrated_bracket_ms(device, bracketed_launch_ms):
     return min(est, 0.1 * bracketed_launch_ms)
 
 
-def executed_launch_flops(label, wino=True):
+def executed_launch_flops(label, wino=True, ctx=None, family=None):
     """FLOPs one labelled launch issues on the matrix cores: the algorithmic count, except that a stride-1 3x3 convolution
-    in the Winograd F(2x2, 3x3) form issues 4 instead of 9 multiply-adds per output and channel pair, a k x 3 / 3 x k one in the
-    1-D F(2, 3) form two thirds of the direct count."""
-    fl = algorithmic_flops(label)
+    in the Winograd F(2x2, 3x3) form (family conv_wino) issues 4 instead of 9 multiply-adds per output and channel pair, a
+    k x 3 / 3 x k one in the 1-D F(2, 3) form (conv_wino1d) two thirds of the direct count.  family = the kernel ops.py ran
+    the label on (profiling.KernelTimer.family); without it the form is inferred from the label's shape as the engine would."""
+    fl = algorithmic_flops(label, ctx)
+    if family is not None:
+        return fl * 4 // 9 if family == "conv_wino" else (fl * 2 // 3 if family == "conv_wino1d" else fl)
     if fl and wino and label.startswith("conv_cl["):
         geo = _conv_geometry(label.split("[", 1)[1].rstrip("]"))
         if geo["ho"] == geo["h"] and geo["wo"] == geo["w"] and geo["cin"] % 16 == 0 and geo["cout"] % 16 == 0 and "+res" not in label[-6:]:
@@ -181,6 +192,31 @@ def executed_launch_flops(label, wino=True):
         if (geo["kh"], geo["kw"]) == (3, 3) and geo["ho"] == geo["h"] and geo["wo"] == geo["w"] and geo["cin"] % 16 == 0 and geo["cout"] % 16 == 0:
             return fl * 4 // 9
     return fl
+
+
+def family_table(summary, family, n_steps, bracket_ms, ctx):
+    """Per kernel FAMILY (one kernel template: conv_wino, conv_wino1d, conv_igemm, point_head, ...), over the labelled launches
+    of `n_steps` steps: launches and summed ms per step (the event bracket's own time taken off every launch), algorithmic
+    and executed FLOPs and algorithmic bytes per step.  summary: KernelTimer.summary(); family: KernelTimer.family."""
+    table = {}
+    for label, (calls, total_ms, _) in summary.items():
+        fam = family.get(label, label.split("[", 1)[0])
+        row = table.setdefault(fam, {"launches": 0.0, "ms": 0.0, "alg_flops": 0.0, "exec_flops": 0.0, "alg_bytes": 0.0, "labels": {}})
+        ms = max(total_ms - calls * min(bracket_ms, 0.1 * total_ms / calls), 0.0) / n_steps
+        per = calls / n_steps
+        row["launches"] += per
+        row["ms"] += ms
+        row["alg_flops"] += per * algorithmic_flops(label, ctx)
+        row["exec_flops"] += per * executed_launch_flops(label, ctx=ctx, family=fam)
+        row["alg_bytes"] += per * algorithmic_bytes(label, ctx)
+        row["labels"][label] = ms
+    return table
+
+
+def dominant_family(table):
+    """The own kernel family with the most time per step (families without a byte / FLOP model are not candidates)."""
+    cand = {k: v for k, v in table.items() if v["alg_bytes"] > 0 or v["alg_flops"] > 0}
+    return max(cand, key=lambda k: cand[k]["ms"]) if cand else None
 
 
 def executed_flops(engine, b, n, t, stem_class_rows):
@@ -255,6 +291,19 @@ def pmc_traffic(label):
         return None
 
 
+def pmc_traffic_family(labels_per_step):
+    """Mean HBM bytes per launch over a family's launches of one step ({label: launches per step}); None unless every label
+    of the family has a PMC row."""
+    total = n = 0.0
+    for label, per in labels_per_step.items():
+        t = pmc_traffic(label)
+        if t is None:
+            return None
+        total += per * t
+        n += per
+    return round(total / n) if n else None
+
+
 def make_frames(n_frames, seq_seed, tta=True):
     """Host preprocessing of a synthetic sequence -> list of (sample, raw_scan, pose)."""
     from streammos_amd import preprocess, synth
@@ -310,60 +359,148 @@ def cpu_baseline(frames, state_dict, n_timed):
                       "(forward + TTA argmax, voting excluded)" % (1, n_timed, FRAME_POINT_NUM)}
 
 
-def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4):
-    """BASELINE configs[4] on ONE GPU (reported beside `value`, never as it): the stage-2 training step of
-    train_StreamMOS_seg.py:58,165-190 -- StreamMOS_seg.AttNet, everything but `refine.*` frozen, SyncBatchNorm conversion +
-    DistributedDataParallel(find_unused_parameters=True) on the 'nccl' (= RCCL) backend with a process group of one rank,
-    model.train(), three chained forwards per step (models/StreamMOS_seg.py:173-196), backward, SGD step -- at the
-    reference's training shape (batch_size_per_gpu 4, Train.frame_point_num 130000, config/StreamMOS_seg.py:5,27) on
-    synthetic scans and seeded targets.  Counts the collectives a step issues (a SyncBatchNorm layer in train mode
-    all_gathers its (mean, invstd, count) in every forward whether or not its weights are frozen)."""
-    import collections
+class _WireCounter:
+    """Counts the collectives a training step puts on the wire, where they are issued: torch.distributed's Python entry points
+    (SyncBatchNorm's forward all_gather and backward all_reduce go through them, torch/nn/modules/_functions.py:65-84), DDP's
+    gradient buckets through a comm hook that wraps the default all-reduce hook, and -- for everything issued from C++ (the
+    used-parameter bitmap of find_unused_parameters=True) -- the process group's own sequence number, which the backend
+    advances once per collective."""
+    NAMES = ("all_gather_into_tensor", "all_gather", "all_reduce", "reduce", "broadcast", "barrier", "reduce_scatter_tensor")
+
+    def __init__(self):
+        import collections
+        self.counts = collections.Counter()
+        self.tag = None
+        self._saved = {}
+
+    def __enter__(self):
+        import torch.distributed as dist
+        for name in self.NAMES:
+            fn = getattr(dist, name, None)
+            if fn is None:
+                continue
+            self._saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name, **kw):
+                self.counts[self.tag or _name] += 1
+                return _fn(*a, **kw)
+            setattr(dist, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        return False
+
+    def ddp_hook(self, state, bucket):
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        self.tag = "ddp_gradient_bucket_all_reduce"
+        try:
+            return default_hooks.allreduce_hook(state, bucket)
+        finally:
+            self.tag = None
+
+    @staticmethod
+    def sequence_number():
+        import torch.distributed as dist
+        try:
+            return int(dist.distributed_c10d._get_default_group()._get_sequence_number_for_group())
+        except Exception:
+            return None
+
+
+def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4, rehearsal=False):
+    """BASELINE configs[4] (reported beside `value`, never as it): the stage-2 training step of
+    train_StreamMOS_seg.py:58,130,143,165-190 -- StreamMOS_seg.AttNet, everything but `refine.*` frozen, SyncBatchNorm
+    conversion + DistributedDataParallel(find_unused_parameters=True), model.train(), three chained forwards per step
+    (models/StreamMOS_seg.py:173-196), backward, SGD step -- at the reference's training shape (batch_size_per_gpu 4,
+    Train.frame_point_num 130000, config/StreamMOS_seg.py:5,27) on synthetic scans and seeded targets.
+
+    Runs on the process group that exists: under `bench.py --gpus N` all N ranks (one RCCL group, 'nccl') train as real DDP --
+    every rank its own samples of the synthetic set (DistributedSampler-style: rank r of W takes samples r, r + W, ...),
+    gradients all-reduced, statistics of every SyncBatchNorm layer all-gathered -- and the step is timed between barriers, MAX
+    over ranks.  Without a group: a one-rank group is created (a one-GPU box).  The collectives are COUNTED ON THE WIRE
+    (_WireCounter), not inferred.  rehearsal=True (bench.py --dry-launch): the same code path on CPU tensors over gloo at a
+    reduced shape, with the GPU-only sampler swapped for the reference's debug torch formulation
+    (deformattn/functions/ms_deform_attn_func.py:41-61, as deformattn/test.py does) -- a test of the launch and the group
+    logic, not a measurement.
+
+    Test knobs (tests/test_gpu_launch.py): SMOS_BENCH_TRAIN_BATCH=<npz> feeds every rank that file's batch dict (REPLICATED:
+    the stage-2 loss -- OHEM top-k + Lovasz -- is a set function of the batch, not a per-sample mean, so only a rank that sees
+    the whole pinned batch can reproduce the pinned loss; DDP then averages identical gradients), SMOS_BENCH_TRAIN_EVAL=1 runs
+    the step in eval mode (the mode the reference fixture tests/golden/training.npz pins stage 2 in);
+    SMOS_BENCH_TRAIN_POINTS / SMOS_BENCH_TRAIN_BATCH_PER_GPU shrink the synthetic shape."""
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel
     from streammos_amd import preprocess, synth
     from streammos_amd.refapi.config import StreamMOS_seg as cfg
     from streammos_amd.refapi.models import StreamMOS_seg
+    on_gpu = device.type == "cuda"
     own_group = not dist.is_initialized()
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    counts = collections.Counter()
+        if on_gpu:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=0, world_size=1)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    fixture = os.environ.get("SMOS_BENCH_TRAIN_BATCH")
+    eval_mode = os.environ.get("SMOS_BENCH_TRAIN_EVAL") == "1"
+    frame_point_num = int(os.environ.get("SMOS_BENCH_TRAIN_POINTS", frame_point_num))       # test knobs: a smaller shape
+    batch = int(os.environ.get("SMOS_BENCH_TRAIN_BATCH_PER_GPU", batch))
+    if rehearsal:
+        frame_point_num, batch = 512, 1
+        import streammos_amd.refapi.deformattn._msda as _msda_mod
+        from streammos_amd.refapi.deformattn.functions import ms_deform_attn_func as _fn
+
+        class _TorchSampler:
+            @staticmethod
+            def apply(value, shapes, lsi, loc, attn, step):
+                return _fn.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+        saved_sampler, _msda_mod.MSDeformAttnFunction = _msda_mod.MSDeformAttnFunction, _TorchSampler
+    wire = _WireCounter()
     try:
         net = StreamMOS_seg.AttNet(cfg.get_config()[2])
         net.load_state_dict(synth.seeded_state_dict(net.state_dict()), strict=True)
         trainable = StreamMOS_seg.freeze_for_stage2(net)
         n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in net.modules())
-        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net).to(device)
-        model = DistributedDataParallel(net, device_ids=[device.index], output_device=device.index, find_unused_parameters=True)
+        if on_gpu:               # torch's SyncBatchNorm exists for GPU modules only: the CPU rehearsal keeps per-rank BatchNorm
+            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        net = net.to(device)
+        if on_gpu:
+            model = DistributedDataParallel(net, device_ids=[device.index], output_device=device.index, find_unused_parameters=True)
+        else:
+            model = DistributedDataParallel(net, find_unused_parameters=True)
+        model.register_comm_hook(None, wire.ddp_hook)
         opt = torch.optim.SGD(trainable, lr=0.02, momentum=0.9, nesterov=True, weight_decay=1e-3)
-        spec = preprocess.VoxelSpec()
-        scans = [synth.synthetic_scan(7000 + k) for k in range(5)]
-        poses = [synth.synthetic_pose(k) for k in range(5)]
-        gen = torch.Generator(device="cpu").manual_seed(11)
         data = {}
-        for i in range(3):                                     # three consecutive samples, chained through the memory
-            idx = preprocess.window_indices(i, 5, 3)
-            smp = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
-            for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"):
-                data["%s_%d" % (k, i)] = torch.from_numpy(np.ascontiguousarray(smp[k][:batch])).to(device)
-            data["pcds_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
-            data["pcds_bev_target_%d" % i] = torch.randint(0, 3, (batch, 256, 256, 1), generator=gen).to(device)
-            data["pcds_bf_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
-        model.train()
-        # Collectives a >= 2-rank run of this step issues (a one-rank group short-cuts them, so they are counted where they
-        # originate): every SyncBatchNorm forward in train mode all_gathers its (mean, invstd, count) -- frozen weights or not
-        # (train_StreamMOS_seg.py:58 calls model.train() on the whole net) --, its backward all_reduces two C-vectors when its
-        # input needs a gradient; DDP all-reduces one bucket of `refine.*` gradients plus, with find_unused_parameters=True,
-        # the used-parameter bitmap; the reference then reduces the scalar loss to rank 0 (train_StreamMOS_seg.py:31-42,69).
-        def bn_hook(mod, inp, out):
-            counts["syncbn_forward_all_gather"] += 1
-            if inp[0].requires_grad:
-                counts["syncbn_backward_all_reduce"] += 1
-        for m in net.modules():
-            if isinstance(m, torch.nn.SyncBatchNorm):
-                m.register_forward_hook(bn_hook)
+        if fixture:
+            with np.load(fixture) as z:
+                data = {k: torch.from_numpy(z[k]).to(device) for k in z.files}
+            batch = int(data["pcds_xyzi_0"].shape[0])
+            frame_point_num = int(data["pcds_xyzi_0"].shape[3])
+        else:
+            spec = preprocess.VoxelSpec()
+            # sample g of the synthetic training set = three consecutive windows of a 5-scan sequence seeded 7000 + 10 g;
+            # rank r takes sample r (+ W, + 2 W, ... for the following steps would be the sampler's job; the bench repeats
+            # one batch per rank, what the reference's DataLoader hands over changes no shape and no collective)
+            base = 7000 + 10 * rank
+            mk = (lambda k: synth.synthetic_scan(base + k, 8, 40)) if rehearsal else (lambda k: synth.synthetic_scan(base + k))
+            scans = [mk(k) for k in range(5)]
+            poses = [synth.synthetic_pose(k) for k in range(5)]
+            gen = torch.Generator(device="cpu").manual_seed(11 + rank)
+            for i in range(3):                                     # three consecutive samples, chained through the memory
+                idx = preprocess.window_indices(i, 5, 3)
+                smp = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num, spec, tta=True)
+                for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord"):
+                    data["%s_%d" % (k, i)] = torch.from_numpy(np.ascontiguousarray(smp[k][:batch])).to(device)
+                data["pcds_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
+                data["pcds_bev_target_%d" % i] = torch.randint(0, 3, (batch, 256, 256, 1), generator=gen).to(device)
+                data["pcds_bf_target_%d" % i] = torch.randint(0, 3, (batch, frame_point_num, 1), generator=gen).to(device)
+        model.train(not eval_mode)
 
         def step():
             loss = model(data)
@@ -371,38 +508,177 @@ def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4):
             loss.backward()
             opt.step()
             return loss
+
+        def fence():
+            if on_gpu:
+                torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                if on_gpu:
+                    torch.cuda.synchronize()
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        counts.clear()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return {"value": round(batch * steps / dt, 3), "unit": "samples/s (one GPU; a sample = 3 chained forwards + backward)",
-                "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "batch_per_gpu": batch, "frame_point_num": frame_point_num,
-                "loss": round(float(loss.detach()), 5), "batchnorm_layers": n_bn, "trainable_tensors": len(trainable),
-                "collectives_per_step_at_2_or_more_ranks": dict({k: v // steps for k, v in sorted(counts.items())},
-                                                                ddp_gradient_bucket_all_reduce=1, ddp_used_parameter_bitmap_all_reduce=1,
-                                                                loss_reduce_to_rank0=1),
-                "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
-                "note": "BASELINE configs[4] on one GPU: stage-2 step (all but refine.* frozen) under SyncBatchNorm + DDP on a "
-                        "one-rank RCCL group, module graph with torch autograd (MIOpen convs; VoxelMaxPool / deformable-attention "
-                        "forward and backward on the HIP kernels); reported beside `value`, never as it"}
+        fence()
+        seq0 = wire.sequence_number()
+        with wire:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            if on_gpu:
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        seq1 = wire.sequence_number()
+        fence()
+        grad_norms = {k: float(p.grad.double().norm()) for k, p in net.named_parameters() if p.grad is not None}
+        t = torch.tensor([dt, float(loss.detach())], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        tmax = t.clone()
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)               # what train_StreamMOS_seg.py:31-42,69 logs: the mean loss
+        dt_max, loss_mean = float(tmax[0]), float(t[1]) / world
+        py = {k: v / steps for k, v in sorted(wire.counts.items())}
+        res = {"value": round(world * batch * steps / dt_max, 3),
+               "unit": "samples/s aggregate over %d rank(s) (a sample = 3 chained forwards + backward)" % world,
+               "world": world, "backend": "%s%s" % (backend, " (= RCCL)" if backend == "nccl" else ""),
+               "ms_per_step": round(1e3 * dt_max / steps, 2), "steps": steps, "batch_per_gpu": batch, "frame_point_num": frame_point_num,
+               "loss": round(loss_mean, 6), "loss_rank0": round(float(loss.detach()), 6), "batchnorm_layers": n_bn,
+               "trainable_tensors": len(trainable), "mode": "eval" if eval_mode else "train",
+               "collectives_per_step_on_the_wire": dict(
+                   py, process_group_sequence_numbers=None if seq0 is None or seq1 is None else (seq1 - seq0) / steps,
+                   note="counted where issued during the timed steps of rank 0: torch.distributed's Python entry points "
+                        "(SyncBatchNorm: one all_gather of (mean, invstd, count) per layer and forward when world > 1, two-vector "
+                        "all_reduce per backward whose input needs a gradient), DDP gradient buckets through a comm hook; "
+                        "process_group_sequence_numbers = the backend's own collective counter over the same steps (adds what "
+                        "C++ issues: DDP's used-parameter bitmap all-reduce)"),
+               "grad_norms": {k: round(v, 8) for k, v in grad_norms.items()},
+               "data": "fixture %s replicated on every rank" % os.path.basename(fixture) if fixture else
+                       "synthetic, per-rank samples (rank r seeds 7000 + 10 r)",
+               "note": "BASELINE configs[4]: stage-2 step (all but refine.* frozen) under SyncBatchNorm + DDP, module graph with torch "
+                       "autograd (MIOpen convs; VoxelMaxPool / deformable-attention forward and backward on the HIP kernels); reported "
+                       "beside `value`, never as it"}
+        if on_gpu:
+            res["hbm_allocated_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
+        if rehearsal:
+            res["rehearsal"] = ("CPU tensors over gloo, N = %d, batch %d, torch formulation of the sampler, per-rank BatchNorm (torch's "
+                                "SyncBatchNorm is GPU-only): launch-path test, not a measurement" % (frame_point_num, batch))
+        return res
     finally:
+        if rehearsal:
+            _msda_mod.MSDeformAttnFunction = saved_sampler
         if own_group:
             dist.destroy_process_group()
 
 
+def family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed_family):
+    """The bench line's `roofline`: the dominant KERNEL of the step, chosen from SERIAL steady-state steps.
+
+    Eight steps of StreamRunner(pipeline=False) (one stream, the two pipeline stages one after the other) run right after the
+    timed region with a HIP-event bracket around every labelled launch, on the stream the launch goes to.  The launches are
+    summed per kernel family (= kernel template: the 36 Winograd launches of a step carry 14 labels but are ONE kernel); the
+    family with the most time per step is the dominant kernel.  A serial step is also what `rocprofv3 --kernel-trace` of
+    `bench.py --no-pipeline` measures, so the figures can be checked against profiles/rNN_label_durations.csv family by family.
+    In the timed (two-stream) region a launch shares the CUs with the other stage's kernels -- a property of the pipelining,
+    not of the kernel; in_step_* keeps that figure when the warm-up's guess of the family was right.
+
+    `frac`: an MFMA-bound family is priced on the FLOPs it EXECUTES on the matrix cores (a Winograd launch issues 4/9 of the
+    direct count); `algorithmic_frac` beside it counts the direct-form FLOPs and may exceed 1."""
+    from streammos_amd import profiling, streaming
+    serial = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=False)
+    n_ser = 8
+    for i in range(2):
+        serial.step(*dev_frames[i % len(dev_frames)])
+    torch.cuda.synchronize()
+    with profiling.kernel_timer() as kt_ser:
+        for i in range(n_ser):
+            serial.step(*dev_frames[(2 + i) % len(dev_frames)])
+    ser = kt_ser.summary()
+    serial.close()
+    del serial
+    if not ser:
+        return None, None
+    # what an (event, launch, event) bracket adds to a launch (the event packets' own processing; ~7 % of a 40 us launch): a
+    # ~30 us device copy 64 times, every launch in its own bracket vs. all 64 in ONE bracket.  Subtracted (never more than a
+    # tenth of a launch), and reported.
+    bracket_ms = min(event_bracket_overhead(device) for _ in range(3))
+    table = family_table(ser, kt_ser.family, n_ser, bracket_ms, ctx)
+    fam = dominant_family(table)
+    families = {k: {"launches_per_step": round(v["launches"], 2), "ms_per_step": round(v["ms"], 4)}
+                for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])}
+    if fam is None:
+        return None, families
+    row = table[fam]
+    sec = row["ms"] * 1e-3
+    t_hbm, t_mfma = row["alg_bytes"] / (HBM_PEAK_GBS * 1e9), row["exec_flops"] / (FP32_PEAK_TFLOPS * 1e12)
+    n = row["launches"]
+    labels_per_step = {l: ser[l][0] / n_ser for l in row["labels"]}
+    roof = {"kernel": fam, "launches_per_step": round(n, 2), "ms_per_step": round(row["ms"], 4),
+            "avg_launch_ms": round(row["ms"] / n, 5), "labels": len(row["labels"]),
+            "algorithmic_flops_per_launch": round(row["alg_flops"] / n), "executed_flops_per_launch": round(row["exec_flops"] / n),
+            "algorithmic_bytes_per_launch": round(row["alg_bytes"] / n), "traffic": pmc_traffic_family(labels_per_step),
+            "hbm_floor_ms_per_step": round(1e3 * t_hbm, 4), "mfma_floor_ms_per_step": round(1e3 * t_mfma, 4),
+            "event_bracket_ms": round(bracket_ms, 5), "serial_steps": n_ser,
+            "share_of_serial_labelled_ms": round(row["ms"] / max(sum(v["ms"] for v in table.values()), 1e-9), 4),
+            "clock": "HIP events (torch.cuda.Event) on the launch stream around every labelled launch of %d serial steps "
+                     "(StreamRunner(pipeline=False): one stream) right after the timed region, summed per kernel family; the "
+                     "bracket's own time (event_bracket_ms) taken off every launch = what rocprofv3 --kernel-trace of `bench.py "
+                     "--no-pipeline` reports (profiles/rNN_label_durations.csv, family rows); in_step_* = the same launches "
+                     "inside the timed two-stream region, where they share the CUs with the other stage's kernels" % n_ser}
+    if t_mfma > t_hbm:
+        ach = row["exec_flops"] / sec / 1e12
+        roof.update({"bound": "mfma", "achieved": round(ach, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                     "algorithmic_frac": round(row["alg_flops"] / sec / 1e12 / FP32_PEAK_TFLOPS, 4),
+                     "frac_counts": "executed FLOPs (what the matrix cores issue); algorithmic_frac = direct-form FLOPs"})
+    else:
+        ach = row["alg_bytes"] / sec / 1e9
+        roof.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})
+    if ctx.get("stem_rows") is not None:
+        roof["stem_rows_per_launch"] = round(ctx["stem_rows"])
+    # per label of the family (serial steps): where inside the family the time goes
+    roof["by_label"] = {l: {"launches_per_step": round(labels_per_step[l], 2), "ms_per_launch": round(ms / labels_per_step[l], 5),
+                            "frac": round((executed_launch_flops(l, ctx=ctx, family=fam) / FP32_PEAK_TFLOPS / 1e12 if roof["bound"] == "mfma"
+                                           else algorithmic_bytes(l, ctx) / HBM_PEAK_GBS / 1e9) / max(ms / labels_per_step[l] * 1e-3, 1e-12), 4)}
+                        for l, ms in sorted(row["labels"].items(), key=lambda kv: -kv[1])}
+    # the same launches inside the timed two-stream region
+    mine = {l: v for l, v in timed.items() if timed_family.get(l) == fam}
+    if mine:
+        tot = sum(v[1] - v[0] * min(bracket_ms, 0.1 * v[2]) for v in mine.values()) * 1e-3
+        work = sum(v[0] * (executed_launch_flops(l, ctx=ctx, family=fam) if roof["bound"] == "mfma" else algorithmic_bytes(l, ctx))
+                   for l, v in mine.items())
+        peak = FP32_PEAK_TFLOPS * 1e12 if roof["bound"] == "mfma" else HBM_PEAK_GBS * 1e9
+        roof["in_step_ms_per_step"] = round(1e3 * tot / args.steps, 4)
+        roof["in_step_frac"] = round(work / max(tot, 1e-12) / peak, 4)
+    # and the family's largest label re-run 30 times back to back with its own operands (inputs and weights hot in L2 /
+    # Infinity Cache): an upper bound of what the kernel does, reported beside `frac`, never as it
+    top = max(row["labels"], key=lambda l: row["labels"][l])
+    if top.startswith("conv_cl"):
+        profiling.request_replay(top)
+        one_step(0)
+        one_step(1)
+        again = profiling.replay_of(top)
+        if again is not None:
+            torch.cuda.synchronize()
+            with profiling.kernel_timer(only=top) as kt_iso:
+                for _ in range(30):
+                    again()
+            hot = kt_iso.summary()[top][2]
+            work = executed_launch_flops(top, ctx=ctx, family=fam) / FP32_PEAK_TFLOPS / 1e12 if roof["bound"] == "mfma" \
+                else algorithmic_bytes(top, ctx) / HBM_PEAK_GBS / 1e9
+            roof["hot_replay"] = {"label": top, "launch_ms": round(hot, 4), "frac": round(work / (hot * 1e-3), 4)}
+    return roof, families
+
+
 def dry_launch(args):
     """The launch path without the GPU: every rank joins a gloo group, the barrier-bracketed "timed region" is K
-    barriers, the MAX over ranks is taken as in the real run and rank 0 prints the line with the group's real size."""
+    barriers, the MAX over ranks is taken as in the real run and rank 0 prints the line with the group's real size.
+    With --train-steps K the ranks also run K stage-2 DDP steps on CPU tensors through the same train_bench the GPU run uses
+    (rehearsal shape), and rank 0 reports `stage2_training` with the world size of the group that trained."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     elapsed = 0.0
+    training = None
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
         dist.barrier()
@@ -412,11 +688,17 @@ def dry_launch(args):
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, world = float(t.item()), dist.get_world_size()
+    if args.train_steps:
+        training = train_bench(torch.device("cpu"), args.train_steps, warmup=0, rehearsal=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "dry launch (no GPU work)", "value": None, "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "dry_launch": True, "barrier_ms": round(1e3 * elapsed / max(args.steps, 1), 4),
-                          "config": {"parallelism": "sequence-shard x%d" % world}}), flush=True)
+        line = {"metric": "dry launch (no GPU work)", "value": None, "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "dry_launch": True, "barrier_ms": round(1e3 * elapsed / max(args.steps, 1), 4),
+                "config": {"parallelism": "sequence-shard x%d" % world}}
+        if training is not None:
+            line["stage2_training"] = training
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -438,8 +720,9 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=4, help="timed scans of the CPU baseline (0 = skip); 4 scans = about 15 s")
     ap.add_argument("--streams", type=int, default=0,
                     help="also time S concurrent sequences batched on the GPU (BASELINE configs[2]); reported beside value")
-    ap.add_argument("--train-steps", type=int, default=3,
-                    help="timed stage-2 training steps on one GPU (BASELINE configs[4]; 0 = skip); reported beside value")
+    ap.add_argument("--train-steps", type=int, default=None,
+                    help="timed stage-2 DDP training steps on all ranks (BASELINE configs[4]; 0 = skip; default 3, 0 with "
+                         "--dry-launch); reported beside value")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only rehearse the rank launch: gloo ranks join the group, time a barrier, rank 0 prints n_gpus")
     ap.add_argument("--label-log", default=None,
@@ -451,6 +734,8 @@ def main():
     if args.gpus > 1 and not launch.under_launcher():
         # no launcher around us: become the launcher.  Nothing above this line touches the GPU (importing torch does not).
         sys.exit(launch.self_launch(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+    if args.train_steps is None:
+        args.train_steps = 0 if args.dry_launch else 3
     if args.dry_launch:
         return dry_launch(args)
 
@@ -500,15 +785,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up: also finds the dominant hand-written kernel
+    # warm-up.  Its per-family sums only decide which family's launches carry HIP-event brackets inside the timed region
+    # (in_step_*); the roofline's kernel is chosen afterwards, from serial steady-state steps (family_roofline below).
     with profiling.kernel_timer() as kt:
         for i in range(args.warmup):
             one_step(i)
     warm = kt.summary()
-    # dominant = the single-launch hand-written kernel with the most time (the stem_* spans cover several launches whose
-    # bytes depend on the occupancy of the frame; they are listed in hip_kernel_ms_per_step_warmup)
-    single = {k: v for k, v in warm.items() if not k.startswith("stem_")}
-    dominant = max(single, key=lambda k: single[k][1]) if single else None
+    warm_family = dominant_family(family_table(warm, kt.family, max(args.warmup, 1), 0.0, None)) if warm else None
 
     if args.label_log and rank == 0:
         with profiling.kernel_timer() as kt_seq:
@@ -520,7 +803,7 @@ def main():
     t0 = time.perf_counter()
     half = args.steps // 2
     e_mid, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with profiling.kernel_timer(only=dominant) as kt:
+    with profiling.kernel_timer(only=(lambda label, fam: fam == warm_family)) as kt:
         for i in range(args.steps):
             if i == half:
                 e_mid.record()                 # on the runner's main stream, behind step `half - 1`
@@ -529,7 +812,7 @@ def main():
         enqueue = time.perf_counter() - t0     # host time to issue all steps (the GPU may still be running)
         sync()
         elapsed = time.perf_counter() - t0
-    timed = kt.summary()
+    timed, timed_family = kt.summary(), dict(kt.family)
     # the second half of the timed region alone: the shader clock is still ramping through the first steps of a short run
     # (2.09 -> 2.38 GHz, tools/conv_stamps.py); reported beside ms_per_step, which stays the whole region
     second_half_ms = e_mid.elapsed_time(e_end) / (args.steps - half) if args.steps - half > 0 and half > 0 else None
@@ -540,6 +823,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    line = None
     if rank == 0:
         value = world * args.steps / elapsed
         eng = getattr(model, "_engine", None)
@@ -551,130 +835,8 @@ def main():
             metas = [_ops.stem_plan(d["pcds_coord"], *eng.bev_hw).meta.cpu().numpy() for d, _ in dev_frames]
             stem_class_rows = tuple(float(np.mean([m[8 + c] - m[4 + c] for m in metas])) for c in range(4))
             ctx["stem_rows"] = float(np.mean([m[11] for m in metas]))
-        roof = None
-        if dominant and dominant in timed:
-            calls, total_ms, mean_ms = timed[dominant]
-            ab = algorithmic_bytes(dominant, ctx)
-            af = algorithmic_flops(dominant, ctx)
-            t_hbm, t_mfma = ab / (HBM_PEAK_GBS * 1e9), af / (FP32_PEAK_TFLOPS * 1e12)
-            common = {"kernel": dominant, "traffic": pmc_traffic(dominant), "algorithmic_bytes_per_launch": ab,
-                      "algorithmic_flops_per_launch": af, "hbm_floor_ms": round(1e3 * t_hbm, 4),
-                      "mfma_floor_ms": round(1e3 * t_mfma, 4), "avg_launch_ms": round(mean_ms, 4), "launches": calls,
-                      "clock": "HIP events (torch.cuda.Event) recorded around the launch on the stream handed to the C ABI, "
-                               "inside the timed region; profiles/r02*_kernel_stats.csv holds rocprofv3's mean for the same kernel"}
-            if t_mfma > t_hbm:
-                # the matrix-core time of the launch exceeds its HBM time: an MFMA-bound kernel
-                achieved = af / (mean_ms * 1e-3) / 1e12
-                roof = dict({"bound": "mfma", "achieved": round(achieved, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / FP32_PEAK_TFLOPS, 4)}, **common)
-            else:
-                achieved = ab / (mean_ms * 1e-3) / 1e9
-                roof = dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 4)}, **common)
-            if ctx.get("stem_rows") is not None:
-                roof["stem_rows_per_launch"] = round(ctx["stem_rows"])
-        if roof:
-            # The same launch inside a SERIAL step (one stream, the two pipeline stages one after the other): in the timed
-            # region it shares the CUs with the other stage's kernels, which stretches its HIP-event time by about 2x --
-            # a property of the pipelining, not of the kernel.  The serial step is also what `rocprofv3 --kernel-trace` of
-            # `bench.py --no-pipeline` measures, so `frac` can be checked against profiles/rNN_label_durations.csv
-            # (tools/profile_round.sh), row by row.  in_step_* keeps the figure from the timed (pipelined) region.
-            serial = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=False)
-            for i in range(2):
-                serial.step(*dev_frames[i % len(dev_frames)])
-            torch.cuda.synchronize()
-            with profiling.kernel_timer(only=dominant) as kt_ser:
-                for i in range(8):
-                    serial.step(*dev_frames[(2 + i) % len(dev_frames)])
-            ser = kt_ser.summary().get(dominant)
-            # what an (event, launch, event) bracket adds to a launch (the event packets' own processing; ~7 % of a 40 us
-            # launch): a ~30 us device copy 64 times, every launch in its own bracket vs. all 64 in ONE bracket (the queue
-            # never drains: the copies run back to back).  Subtracted, and reported.  (Two records with nothing between them
-            # are no measure of it: 2.7 us on one box, 10.8 us on the next.)
-            bracket_ms = calibrated_bracket_ms(device, ser[2]) if ser is not None else 0.0
-            if ser is not None:
-                iso = max(ser[2] - bracket_ms, 1e-6)
-                roof["event_bracket_ms"] = round(bracket_ms, 5)
-                roof["serial_step_launch_ms_with_bracket"] = round(ser[2], 4)
-                roof["in_step_launch_ms"] = roof["avg_launch_ms"]
-                roof["in_step_frac"] = roof["frac"]
-                roof["serial_step_launch_ms"] = round(iso, 4)
-                if roof["bound"] == "mfma":
-                    ach = roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12
-                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / FP32_PEAK_TFLOPS, 4)
-                else:
-                    ach = roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9
-                    roof["achieved"], roof["frac"] = round(ach, 1), round(ach / HBM_PEAK_GBS, 4)
-                roof["avg_launch_ms"] = round(iso, 4)
-                roof["launches"] = ser[0]
-                if roof["bound"] == "mfma":
-                    # `achieved` counts the ALGORITHMIC FLOPs of the layer (2 x 9 multiply-adds per output and channel pair for a
-                    # 3x3 convolution); a Winograd launch issues 4/9 of them, so its algorithmic rate may pass the dense peak.
-                    # What the matrix cores really did:
-                    ex = executed_launch_flops(dominant, wino=getattr(eng, "wino", False))
-                    roof["executed_flops_per_launch"] = ex
-                    roof["executed_frac"] = round(ex / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-                roof["clock"] = ("HIP events (torch.cuda.Event) on the launch stream around every launch of the dominant label in 8 "
-                                 "serial steps (StreamRunner(pipeline=False): one stream) right after the timed region = what "
-                                 "rocprofv3 --kernel-trace of `bench.py --no-pipeline` reports per launch "
-                                 "(profiles/rNN_label_durations.csv); in_step_* = the same launch inside the timed two-stream "
-                                 "region, where it shares the CUs with the other stage's kernels")
-            serial.close()
-            del serial
-        if roof and dominant.startswith("conv_cl"):
-            # and re-run 30 times back to back with its own operands (inputs and weights hot in L2 / Infinity Cache): an upper
-            # bound of what the kernel does, reported beside `frac`, never as it
-            profiling.request_replay(dominant)
-            one_step(0)
-            one_step(1)
-            again = profiling.replay_of(dominant)
-            if again is not None:
-                torch.cuda.synchronize()
-                with profiling.kernel_timer(only=dominant) as kt_iso:
-                    for _ in range(30):
-                        again()
-                hot = kt_iso.summary()[dominant][2]
-                roof["hot_replay_launch_ms"] = round(hot, 4)
-                roof["hot_replay_frac"] = round((roof["algorithmic_flops_per_launch"] / FP32_PEAK_TFLOPS / 1e12 if roof["bound"] == "mfma"
-                                                 else roof["algorithmic_bytes_per_launch"] / HBM_PEAK_GBS / 1e9) / (hot * 1e-3), 4)
-        if roof and dominant.startswith("point_head") and eng is not None:
-            # the same launch alone on the GPU (in the timed region it shares the CUs with the other pipeline stage)
-            from streammos_amd import ops as _ops
-            d0 = dev_frames[0][0]
-            bs, n = d0["pcds_xyzi"].shape[0], d0["pcds_xyzi"].shape[3]
-            rows = torch.randn((bs, n, 192), dtype=torch.float32, device=device)
-            torch.cuda.synchronize()
-            with profiling.kernel_timer(only=dominant) as kt_iso:
-                for _ in range(20):
-                    _ops.point_head(rows, eng.head_w[0], eng.head_w[1])
-            iso = kt_iso.summary()[dominant][2]
-            roof["isolated_launch_ms"] = round(iso, 4)
-            roof["isolated_frac"] = round(roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-        if roof and dominant.startswith("pointnet_scatter") and eng is not None:
-            from streammos_amd import ops as _ops
-            d0 = dev_frames[0][0]
-            bs, t, _, n = d0["pcds_xyzi"].shape[:4]
-            rows = torch.empty((bs, n, 192), dtype=torch.float32, device=device)
-            compact = eng.sparse_stem and eng.stem_w is not None        # the form the engine launches (engine._encode_cl)
-            if compact:
-                plan = _ops.stem_plan(d0["pcds_coord"], *eng.bev_hw, row_floats=t * 64)
-            else:
-                bev = torch.empty((bs,) + tuple(eng.bev_hw) + (t * 64,), dtype=torch.float32, device=device)
-            torch.cuda.synchronize()
-            with profiling.kernel_timer(only=dominant) as kt_iso:
-                for _ in range(20):
-                    if compact:
-                        _ops.pointnet_scatter_rows(d0["pcds_xyzi"], d0["pcds_coord"], eng.pp1[0], eng.pp1[1], eng.pp2[0],
-                                                   eng.pp2[1], plan, pts_out=rows[:, :, :64])
-                    else:
-                        _ops.pointnet_scatter(d0["pcds_xyzi"], d0["pcds_coord"], eng.pp1[0], eng.pp1[1], eng.pp2[0], eng.pp2[1],
-                                              bev, pts_out=rows[:, :, :64], zero_fill=True)
-            iso = kt_iso.summary()[dominant][2]
-            roof["isolated_launch_ms"] = round(iso, 4)
-            if roof["bound"] == "mfma":
-                roof["isolated_frac"] = round(roof["algorithmic_flops_per_launch"] / (iso * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-            else:
-                roof["isolated_frac"] = round(roof["algorithmic_bytes_per_launch"] / (iso * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            ctx["stem_class_rows"] = stem_class_rows
+        roof, families = family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed_family)
         exec_tflop = None
         if eng is not None and eng.layout == "cl":
             d0 = dev_frames[0][0]
@@ -706,6 +868,8 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "second_half_ms_per_step": None if second_half_ms is None else round(second_half_ms, 3),
             "stem_rows_per_launch": None if ctx.get("stem_rows") is None else round(ctx["stem_rows"]),
+            "stem_class_rows": [round(r) for r in stem_class_rows],
+            "kernel_families_serial": families,
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if world == 1 and not args.no_raw:
@@ -752,20 +916,25 @@ def main():
                                        "ms_per_batched_step": round(1e3 * dt / n_it, 3),
                                        "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
                                        "note": "BASELINE configs[2]; reported beside `value`, never as `value`"}
-        if world == 1 and args.train_steps > 0:
-            runner = dev_frames = None            # the inference buffers are not needed any more
-            torch.cuda.empty_cache()
-            try:
-                line["stage2_training"] = train_bench(device, args.train_steps)
-            except Exception as e:          # never lose the headline line to the side measurement
-                line["stage2_training"] = {"error": repr(e)[:300]}
-        if world == 1 and args.cpu_scans > 0:
-            line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
-        print(json.dumps(line), flush=True)
 
+    if args.train_steps > 0:
+        # configs[4]: every rank of the group trains (real DDP over RCCL when world > 1); rank 0 reports
+        runner = dev_frames = None            # the inference buffers are not needed any more
+        torch.cuda.empty_cache()
+        try:
+            res = train_bench(device, args.train_steps)
+        except Exception as e:          # never lose the headline line to the side measurement
+            res = {"error": repr(e)[:300]}
+        if rank == 0:
+            line["stage2_training"] = res
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if rank == 0:
+        if args.cpu_scans > 0:
+            # rank 0 alone, after the group is gone (the other ranks have left: the host cores are free)
+            line["cpu_baseline"] = cpu_baseline(frames, state, args.cpu_scans)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -567,14 +567,14 @@ def conv_rows_cl(x, wprep, bias, act, cout, kernel, mt=1, residual=None, out=Non
             residual.data_ptr() if residual is not None else None, _cl("conv_rows_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_rows_cl", out), b, h, w, cin, cout, kh, kw, int(mt), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
-    with _on(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label, "conv_rows"):
         rc = lib.smos_conv_rows_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_rows_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)
 
         def again(keep=keep):
-            with _on(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label, "conv_rows"):
                 _lib.check(lib.smos_conv_rows_cl(*args, _stream(keep[0])), "smos_conv_rows_cl")
         profiling.offer_replay(label, again)
     return out
@@ -626,14 +626,14 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
             residual.data_ptr() if residual is not None else None, _cl("conv_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
-    with _on(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label, "conv_igemm"):
         rc = lib.smos_conv_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)          # the closure keeps the operands alive
 
         def again(keep=keep):
-            with _on(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label, "conv_igemm"):
                 _lib.check(lib.smos_conv_cl(*args, _stream(keep[0])), "smos_conv_cl")
         profiling.offer_replay(label, again)
     return out
@@ -698,14 +698,14 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
             out.data_ptr(), _cl("conv_wino_cl", out), b, h, w, cin, cout, int(mb), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
     fn = lib.smos_conv_wino_cl
-    with _on(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label, "conv_wino"):
         rc = fn(*args, _stream(x))
     _lib.check(rc, "smos_conv_wino_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)
 
         def again(keep=keep):
-            with _on(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label, "conv_wino"):
                 _lib.check(fn(*args, _stream(keep[0])), "smos_conv_wino_cl")
         profiling.offer_replay(label, again)
     return out
@@ -1119,14 +1119,14 @@ def conv_wino1d_cl(x, wprep, bias, act, cout, kernel, mb=2, out=None):
     args = (x.data_ptr(), _cl("conv_wino1d_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             out.data_ptr(), _cl("conv_wino1d_cl", out), b, h, w, cin, cout, kh, kw, int(mb), int(act))
     fn = lib.smos_conv_wino1d_cl
-    with _on(x.device), profiling.span(label):
+    with _on(x.device), profiling.span(label, "conv_wino1d"):
         rc = fn(*args, _stream(x))
     _lib.check(rc, "smos_conv_wino1d_cl")
     if profiling._replay_label == label:
         keep = (x, wprep, bias, out)
 
         def again(keep=keep):
-            with _on(keep[0].device), profiling.span(label):
+            with _on(keep[0].device), profiling.span(label, "conv_wino1d"):
                 _lib.check(fn(*args, _stream(keep[0])), "smos_conv_wino1d_cl")
         profiling.offer_replay(label, again)
     return out

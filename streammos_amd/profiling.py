@@ -13,17 +13,26 @@ _replay_label = None      # label whose next launch is kept (closure over its ar
 _replay = {}
 
 
+def family_of(label, family=None):
+    """Kernel family of a launch label: what ops.py names (the convolutions share the label prefix ``conv_cl[`` but run on
+    four kernels: conv_wino, conv_wino1d, conv_igemm, conv_rows), else the label's name in front of the shape."""
+    return family if family is not None else label.split("[", 1)[0]
+
+
 class KernelTimer:
     def __init__(self, only=None):
-        self.only = only            # label filter (None = every launch)
+        self.only = only            # filter: None = every launch, a label, or a callable (label, family) -> bool
         self.events = {}            # label -> list of (start, stop)
         self.sequence = []          # labels in launch order
+        self.family = {}            # label -> kernel family
 
     @contextlib.contextmanager
-    def span(self, label):
-        if self.only is not None and label != self.only:
+    def span(self, label, family=None):
+        fam = family_of(label, family)
+        if self.only is not None and not (self.only(label, fam) if callable(self.only) else label == self.only):
             yield
             return
+        self.family[label] = fam
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
@@ -52,10 +61,13 @@ def kernel_timer(only=None):
         _active = prev
 
 
-def span(label):
+_NULL = contextlib.nullcontext()
+
+
+def span(label, family=None):
     if _active is None or torch.cuda.is_current_stream_capturing():
-        return contextlib.nullcontext()
-    return _active.span(label)
+        return _NULL
+    return _active.span(label, family)
 
 
 def request_replay(label):

@@ -69,3 +69,55 @@ def test_run_sequence_gpus_2_shards_whole_sequences(tmp_path):
                 a = np.fromfile(tmp_path / "two" / name / sub / ("%06d.label" % k), dtype=np.uint32)
                 b = np.fromfile(tmp_path / "one" / name / sub / ("%06d.label" % k), dtype=np.uint32)
                 assert a.shape == b.shape and np.array_equal(a, b), (name, k, sub)
+
+
+def test_bench_gpus_2_trains_stage2_as_ddp_and_reproduces_the_pinned_loss(tmp_path, golden):
+    """`bench.py --gpus 2 --train-steps 1`: after the inference timing BOTH ranks run the stage-2 step as real DDP on the group
+    they already form (train_StreamMOS_seg.py:130,143,176-177), rank 0 reports `stage2_training` with the group's size, and an
+    N > 1 line also carries `roofline` and `cpu_baseline`.  Fed the batch of tests/golden/training.npz (written by the
+    reference) in the mode that fixture pins stage 2 in (eval), every rank must reproduce the reference's loss, and the
+    gradients DDP leaves behind after its all-reduce must have the reference's norms.  (The batch is replicated, not sharded:
+    OHEM top-k + Lovasz are set functions of the batch, so only a rank that sees the whole pinned batch can meet the pinned
+    number; the average of identical gradients is what the all-reduce must return.)"""
+    from tests import cases
+    nb = cases.training_batch()
+    np.savez(tmp_path / "batch.npz", **nb)
+    env = dict(_env(), SMOS_BENCH_TRAIN_BATCH=str(tmp_path / "batch.npz"), SMOS_BENCH_TRAIN_EVAL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+                          "--cpu-scans", "1", "--no-raw", "--train-steps", "1"], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = lines[0]
+    tr = line["stage2_training"]
+    assert "error" not in tr, tr
+    g = golden("training")
+    want = float(g["stage2_eval_loss"])
+    print("2-rank stage-2 step: loss %.6f (rank 0 %.6f) vs the reference's %.6f; %s ms/step; collectives %s"
+          % (tr["loss"], tr["loss_rank0"], want, tr["ms_per_step"], {k: v for k, v in tr["collectives_per_step_on_the_wire"].items() if k != "note"}))
+    assert line["n_gpus"] == 2 and tr["world"] == 2 and tr["mode"] == "eval"
+    assert abs(tr["loss"] - want) <= 1e-4 * abs(want) and abs(tr["loss_rank0"] - want) <= 1e-4 * abs(want)
+    assert sorted(tr["grad_norms"]) == sorted(str(k) for k in g["stage2_params_with_grad"])
+    for k, v in tr["grad_norms"].items():
+        ref = float(g["stage2_eval_grad_norm_%s" % k])
+        assert abs(v - ref) <= 2e-3 * max(ref, 1e-12), (k, v, ref)
+    assert tr["collectives_per_step_on_the_wire"]["ddp_gradient_bucket_all_reduce"] >= 1
+    # the N > 1 line is complete: the dominant kernel's roofline and the CPU baseline ride along
+    assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
+def test_bench_gpus_2_train_mode_counts_syncbn_collectives_on_the_wire():
+    """The same entry in TRAIN mode on per-rank synthetic samples at a small shape: SyncBatchNorm really synchronises (one
+    all_gather per layer and forward, counted where torch.distributed issues it), both ranks finish with a finite loss."""
+    env = dict(_env(), SMOS_BENCH_TRAIN_POINTS="4096", SMOS_BENCH_TRAIN_BATCH_PER_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+                          "--cpu-scans", "0", "--no-raw", "--train-steps", "1"], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    tr = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][-1]["stage2_training"]
+    assert "error" not in tr, tr
+    wire = tr["collectives_per_step_on_the_wire"]
+    print("train mode, 2 ranks: %s" % {k: v for k, v in wire.items() if k != "note"})
+    assert tr["world"] == 2 and tr["mode"] == "train" and np.isfinite(tr["loss"])
+    gathers = wire.get("all_gather", 0) + wire.get("all_gather_into_tensor", 0)
+    assert gathers == 3 * tr["batchnorm_layers"]                      # three chained forwards per step
+    assert wire["ddp_gradient_bucket_all_reduce"] >= 1

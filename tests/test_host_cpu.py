@@ -242,6 +242,24 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
+def test_bench_gpus_2_dry_launch_trains_stage2_on_both_ranks():
+    """`bench.py --gpus 2 --dry-launch --train-steps 1`: the ranks the program started itself form one group and run the
+    stage-2 DDP step through bench.train_bench (CPU tensors over gloo at the rehearsal shape); rank 0 reports the size of the
+    group that trained and the collectives it counted on the wire (configs[4] had no multi-rank entry)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--train-steps", "1", "--steps", "2"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    tr = lines[0]["stage2_training"]
+    assert lines[0]["n_gpus"] == 2 and tr["world"] == 2 and tr["backend"] == "gloo" and tr["steps"] == 1
+    assert np.isfinite(tr["loss"]) and tr["trainable_tensors"] == 8 and len(tr["grad_norms"]) == 8
+    wire = tr["collectives_per_step_on_the_wire"]
+    assert wire["ddp_gradient_bucket_all_reduce"] >= 1
+    assert wire["process_group_sequence_numbers"] is None or wire["process_group_sequence_numbers"] >= wire["ddp_gradient_bucket_all_reduce"]
+
+
 def test_self_launch_reports_a_failing_rank(tmp_path):
     """A rank that dies must fail the whole launch (non-zero exit of the parent)."""
     from streammos_amd import launch
@@ -491,3 +509,65 @@ def test_conv_wino1d_prepare_operand_order_reproduces_the_convolution():
         ops.conv_wino1d_prepare(torch.zeros(16, 32, 7, 3), 2)        # Cout not a multiple of 16 * mb
     assert ops.conv_wino1d_ok((7, 3), 1, 32, 32) and not ops.conv_wino1d_ok((7, 3), 2, 32, 32)
     assert not ops.conv_wino1d_ok((7, 3), 1, 32, 32, residual=object()) and not ops.conv_wino1d_ok((7, 7), 1, 32, 32)
+
+
+def test_bench_roofline_picks_the_dominant_kernel_family_not_a_label():
+    """bench.family_table / dominant_family: the 36 Winograd launches of a step carry 14 labels but are ONE
+    kernel; summed per family they dominate although single labels of other kernels (point_head, upconv_xy) are larger than any
+    one of theirs.  Executed FLOPs follow the kernel the label ran on (4/9 resp. 2/3 of the direct count)."""
+    import bench
+    summary = {
+        "point_head[4x160000]": (8, 8 * 0.30, 0.30),
+        "upconv_xy[4x256x256x128<-128x128+64x64]": (8, 8 * 0.32, 0.32),
+        "conv_cl[4x128x64x64->128x64x64k3x3]": (48, 48 * 0.04, 0.04),
+        "conv_cl[4x64x256x256->128x256x256k3x3]": (8, 8 * 0.19, 0.19),
+        "conv_cl[4x32x256x256->32x256x256k7x3]": (8, 8 * 0.08, 0.08),
+        "conv_cl[4x64x256x256->64x128x128k3x3]": (8, 8 * 0.05, 0.05),
+    }
+    family = {"conv_cl[4x128x64x64->128x64x64k3x3]": "conv_wino", "conv_cl[4x64x256x256->128x256x256k3x3]": "conv_wino",
+              "conv_cl[4x32x256x256->32x256x256k7x3]": "conv_wino1d", "conv_cl[4x64x256x256->64x128x128k3x3]": "conv_igemm"}
+    table = bench.family_table(summary, family, 8, 0.0, None)
+    assert bench.dominant_family(table) == "conv_wino"
+    w = table["conv_wino"]
+    assert abs(w["launches"] - 7) < 1e-9 and abs(w["ms"] - (6 * 0.04 + 0.19)) < 1e-9
+    direct = 6 * 2 * 4 * 64 * 64 * 128 * 128 * 9 + 2 * 4 * 256 * 256 * 128 * 64 * 9
+    assert w["alg_flops"] == direct and w["exec_flops"] == 6 * (2 * 4 * 64 * 64 * 128 * 128 * 9 * 4 // 9) + 2 * 4 * 256 * 256 * 128 * 64 * 9 * 4 // 9
+    assert table["conv_wino1d"]["exec_flops"] * 3 == table["conv_wino1d"]["alg_flops"] * 2
+    assert table["conv_igemm"]["exec_flops"] == table["conv_igemm"]["alg_flops"]
+    # the bracket's own time comes off every launch, never more than a tenth of it
+    t2 = bench.family_table(summary, family, 8, 0.01, None)
+    assert abs(t2["conv_wino"]["ms"] - (6 * (0.04 - 0.004) + 0.19 - 0.01)) < 1e-9
+    # stem_gemm is priced by its FLOPs once the frames' occupancy is known (it was booked as HBM-bound with 0 FLOPs)
+    ctx = {"stem_rows": 200000, "stem_class_rows": (50000, 50000, 50000, 50000)}
+    assert bench.algorithmic_flops("stem_gemm[4x512x512x192]", ctx) == 2 * 50000 * 192 * 32 * (2 + 3 + 3 + 5)
+    assert bench.algorithmic_flops("stem_gemm[4x512x512x192]") == 0
+
+
+def test_release_stream_workspaces_filters_by_device_and_spares_graph_namespaces():
+    """ops.release_stream_workspaces: a (device, stream) release drops that device's eager scratch only -- block
+    tables of another device and entries baked into a runner's captured graphs (namespace ('graph', owner, group)) stay; the
+    owner path drops exactly that runner's."""
+    from streammos_amd import ops
+    saved = (dict(ops._stem_ws), dict(ops._flag_ws))
+    ops._stem_ws.clear()
+    ops._flag_ws.clear()
+    try:
+        t0, t1 = ops.new_block_scratch("cuda:0"), ops.new_block_scratch("cuda:1")
+        for t in (t0, t1):
+            t[(111, 0)] = "eager"
+            t[(111, ("graph", 7, 0))] = "graph7"
+            t[(222, 0)] = "other stream"
+        ops._stem_ws[("cuda:0", 111, "stem_rows", None, 0)] = 1
+        ops._stem_ws[("cuda:1", 111, "stem_rows", None, 0)] = 2
+        ops._stem_ws[("cuda:0", 111, "stem_rows", None, ("graph", 7, 1))] = 3
+        ops.release_stream_workspaces("cuda:0", 111)
+        assert sorted(map(str, t0)) == sorted(map(str, [(111, ("graph", 7, 0)), (222, 0)])) and len(t1) == 3
+        assert sorted(ops._stem_ws.values()) == [2, 3]
+        ops.release_stream_workspaces(owner=7)
+        assert list(t0) == [(222, 0)] and sorted(map(str, t1)) == sorted(map(str, [(111, 0), (222, 0)]))
+        assert list(ops._stem_ws.values()) == [2]
+        ops.release_stream_workspaces()
+        assert not t0 and not t1 and not ops._stem_ws
+    finally:
+        ops._stem_ws.update(saved[0])
+        ops._flag_ws.update(saved[1])
