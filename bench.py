@@ -482,6 +482,7 @@ def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4, rehear
                 data = {k: torch.from_numpy(z[k]).to(device) for k in z.files}
             batch = int(data["pcds_xyzi_0"].shape[0])
             frame_point_num = int(data["pcds_xyzi_0"].shape[3])
+            warmup = 0                          # the pinned numbers are those of the FIRST step from the seeded weights
         else:
             spec = preprocess.VoxelSpec()
             # sample g of the synthetic training set = three consecutive windows of a 5-scan sequence seeded 7000 + 10 g;
