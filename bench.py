@@ -489,7 +489,12 @@ def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4, rehear
             # rank r takes sample r (+ W, + 2 W, ... for the following steps would be the sampler's job; the bench repeats
             # one batch per rank, what the reference's DataLoader hands over changes no shape and no collective)
             base = 7000 + 10 * rank
-            mk = (lambda k: synth.synthetic_scan(base + k, 8, 40)) if rehearsal else (lambda k: synth.synthetic_scan(base + k))
+            if rehearsal:
+                mk = lambda k: synth.synthetic_scan(base + k, 8, 40)
+            elif frame_point_num < 100000:                 # test knob SMOS_BENCH_TRAIN_POINTS: scans that fit the small frame
+                mk = lambda k: synth.synthetic_scan(base + k, 16, 120)
+            else:
+                mk = lambda k: synth.synthetic_scan(base + k)
             scans = [mk(k) for k in range(5)]
             poses = [synth.synthetic_pose(k) for k in range(5)]
             gen = torch.Generator(device="cpu").manual_seed(11 + rank)
