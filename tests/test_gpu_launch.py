@@ -119,5 +119,7 @@ def test_bench_gpus_2_train_mode_counts_syncbn_collectives_on_the_wire():
     print("train mode, 2 ranks: %s" % {k: v for k, v in wire.items() if k != "note"})
     assert tr["world"] == 2 and tr["mode"] == "train" and np.isfinite(tr["loss"])
     gathers = wire.get("all_gather", 0) + wire.get("all_gather_into_tensor", 0)
-    assert gathers == 3 * tr["batchnorm_layers"]                      # three chained forwards per step
+    # three chained forwards per step x the 55 BatchNorm layers on the stage-2 forward path (61 in the model; the rest sit
+    # in branches stage_forward does not run): the figure round 3 inferred from forward hooks, now read off the wire
+    assert gathers == 3 * 55 and gathers <= 3 * tr["batchnorm_layers"]
     assert wire["ddp_gradient_bucket_all_reduce"] >= 1
