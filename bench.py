@@ -575,7 +575,7 @@ def train_bench(device, steps, warmup=1, frame_point_num=130000, batch=4, rehear
             dist.destroy_process_group()
 
 
-def family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed_family):
+def family_roofline(model, device, dev_frames, args, ctx, one_step):
     """The bench line's `roofline`: the dominant KERNEL of the step, chosen from SERIAL steady-state steps.
 
     Eight steps of StreamRunner(pipeline=False) (one stream, the two pipeline stages one after the other) run right after the
@@ -583,8 +583,8 @@ def family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed
     summed per kernel family (= kernel template: the 36 Winograd launches of a step carry 14 labels but are ONE kernel); the
     family with the most time per step is the dominant kernel.  A serial step is also what `rocprofv3 --kernel-trace` of
     `bench.py --no-pipeline` measures, so the figures can be checked against profiles/rNN_label_durations.csv family by family.
-    In the timed (two-stream) region a launch shares the CUs with the other stage's kernels -- a property of the pipelining,
-    not of the kernel; in_step_* keeps that figure when the warm-up's guess of the family was right.
+    (In the timed two-stream region a launch shares the CUs with the other stage's kernels, which stretches it by up to 2x -- a
+    property of the pipelining, not of the kernel; that region carries no event brackets.)
 
     `frac`: an MFMA-bound family is priced on the FLOPs it EXECUTES on the matrix cores (a Winograd launch issues 4/9 of the
     direct count); `algorithmic_frac` beside it counts the direct-form FLOPs and may exceed 1."""
@@ -627,8 +627,7 @@ def family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed
             "clock": "HIP events (torch.cuda.Event) on the launch stream around every labelled launch of %d serial steps "
                      "(StreamRunner(pipeline=False): one stream) right after the timed region, summed per kernel family; the "
                      "bracket's own time (event_bracket_ms) taken off every launch = what rocprofv3 --kernel-trace of `bench.py "
-                     "--no-pipeline` reports (profiles/rNN_label_durations.csv, family rows); in_step_* = the same launches "
-                     "inside the timed two-stream region, where they share the CUs with the other stage's kernels" % n_ser}
+                     "--no-pipeline` reports (profiles/rNN_label_durations.csv, family rows)" % n_ser}
     if t_mfma > t_hbm:
         ach = row["exec_flops"] / sec / 1e12
         roof.update({"bound": "mfma", "achieved": round(ach, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -645,15 +644,6 @@ def family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed
                             "frac": round((executed_launch_flops(l, ctx=ctx, family=fam) / FP32_PEAK_TFLOPS / 1e12 if roof["bound"] == "mfma"
                                            else algorithmic_bytes(l, ctx) / HBM_PEAK_GBS / 1e9) / max(ms / labels_per_step[l] * 1e-3, 1e-12), 4)}
                         for l, ms in sorted(row["labels"].items(), key=lambda kv: -kv[1])}
-    # the same launches inside the timed two-stream region
-    mine = {l: v for l, v in timed.items() if timed_family.get(l) == fam}
-    if mine:
-        tot = sum(v[1] - v[0] * min(bracket_ms, 0.1 * v[2]) for v in mine.values()) * 1e-3
-        work = sum(v[0] * (executed_launch_flops(l, ctx=ctx, family=fam) if roof["bound"] == "mfma" else algorithmic_bytes(l, ctx))
-                   for l, v in mine.items())
-        peak = FP32_PEAK_TFLOPS * 1e12 if roof["bound"] == "mfma" else HBM_PEAK_GBS * 1e9
-        roof["in_step_ms_per_step"] = round(1e3 * tot / args.steps, 4)
-        roof["in_step_frac"] = round(work / max(tot, 1e-12) / peak, 4)
     # and the family's largest label re-run 30 times back to back with its own operands (inputs and weights hot in L2 /
     # Infinity Cache): an upper bound of what the kernel does, reported beside `frac`, never as it
     top = max(row["labels"], key=lambda l: row["labels"][l])
@@ -791,13 +781,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up.  Its per-family sums only decide which family's launches carry HIP-event brackets inside the timed region
-    # (in_step_*); the roofline's kernel is chosen afterwards, from serial steady-state steps (family_roofline below).
+    # warm-up (HIP-event brackets around every labelled launch: reported as hip_kernel_ms_per_step_warmup).  The TIMED region
+    # carries no instrumentation at all -- brackets around the 36 launches of the dominant family cost 0.3 ms of host time per
+    # step and 3 % of `value` when they were tried; the roofline's kernel is chosen and timed afterwards, in serial steady-state
+    # steps (family_roofline).
     with profiling.kernel_timer() as kt:
         for i in range(args.warmup):
             one_step(i)
     warm = kt.summary()
-    warm_family = dominant_family(family_table(warm, kt.family, max(args.warmup, 1), 0.0, None)) if warm else None
 
     if args.label_log and rank == 0:
         with profiling.kernel_timer() as kt_seq:
@@ -809,16 +800,14 @@ def main():
     t0 = time.perf_counter()
     half = args.steps // 2
     e_mid, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with profiling.kernel_timer(only=(lambda label, fam: fam == warm_family)) as kt:
-        for i in range(args.steps):
-            if i == half:
-                e_mid.record()                 # on the runner's main stream, behind step `half - 1`
-            one_step(args.warmup + i)
-        e_end.record()
-        enqueue = time.perf_counter() - t0     # host time to issue all steps (the GPU may still be running)
-        sync()
-        elapsed = time.perf_counter() - t0
-    timed, timed_family = kt.summary(), dict(kt.family)
+    for i in range(args.steps):
+        if i == half:
+            e_mid.record()                 # on the runner's main stream, behind step `half - 1`
+        one_step(args.warmup + i)
+    e_end.record()
+    enqueue = time.perf_counter() - t0     # host time to issue all steps (the GPU may still be running)
+    sync()
+    elapsed = time.perf_counter() - t0
     # the second half of the timed region alone: the shader clock is still ramping through the first steps of a short run
     # (2.09 -> 2.38 GHz, tools/conv_stamps.py); reported beside ms_per_step, which stays the whole region
     second_half_ms = e_mid.elapsed_time(e_end) / (args.steps - half) if args.steps - half > 0 and half > 0 else None
@@ -842,7 +831,7 @@ def main():
             stem_class_rows = tuple(float(np.mean([m[8 + c] - m[4 + c] for m in metas])) for c in range(4))
             ctx["stem_rows"] = float(np.mean([m[11] for m in metas]))
             ctx["stem_class_rows"] = stem_class_rows
-        roof, families = family_roofline(model, device, dev_frames, args, ctx, one_step, timed, timed_family)
+        roof, families = family_roofline(model, device, dev_frames, args, ctx, one_step)
         exec_tflop = None
         if eng is not None and eng.layout == "cl":
             d0 = dev_frames[0][0]

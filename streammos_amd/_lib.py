@@ -52,6 +52,10 @@ SIGNATURES = {
     "smos_conv_wino_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
+    "smos_tfusion_project": [i32, ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, i64, vp],
+    "smos_tfusion_layer_param_floats": [i64],
+    "smos_tfusion_layer_stream_floats": [i64, i32],
+    "smos_tfusion_layer": [vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, ctypes.c_float, ctypes.c_float, vp],
     "smos_conv_wino1d_cl": [vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp],
     "smos_upconv_xpass": [vp, vp, i64, i64, i64, i64, i64, vp],
     "smos_upconv_ypass": [vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
@@ -100,6 +104,8 @@ def load():
     lib.smos_conv_cl_sum_chunks.restype = ctypes.c_int64
     lib.smos_conv_wino_sum_chunks.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
+    lib.smos_tfusion_layer_param_floats.restype = ctypes.c_int64
+    lib.smos_tfusion_layer_stream_floats.restype = ctypes.c_int64
     lib.smos_last_error.argtypes = []
     lib.smos_last_error.restype = ctypes.c_char_p
     _lib = lib

@@ -1,0 +1,415 @@
+// Temporal fusion (DeformAttnLayer, networks/multi_view_encoder.py:285-321; MSDeformAttn's projections,
+// deformattn/modules/ms_deform_attn.py:94-115) as own MFMA kernels for gfx950.  Per frame and layer the reference runs
+//
+//     value = value_proj(src);  qp = [sampling_offsets | attention_weights](query);  att = output_proj(sampler(value, qp))
+//     query = norm1(query + att);  query = norm2(query + linear2(relu(linear1(query))))
+//
+// on a token matrix of B * H * W = 16 384 rows x 128 channels: six small GEMMs, two residual + LayerNorm passes and the
+// sampler per layer (round 3: thirteen library GEMM launches of ~14 us for 0.5 GFLOP each).  Here:
+//
+//   tfusion_project   every token-wise Linear that does NOT depend on the previous layer -- value_proj of BOTH layers (they
+//                     read the same src) and the first layer's offset / logit projection -- as jobs of ONE launch;
+//   (msda_fwd_qp)     the sampler, reading value and qp in place (csrc/msda.hip);
+//   tfusion_layer     output_proj -> + query -> LayerNorm -> linear1 -> ReLU -> linear2 -> + -> LayerNorm (-> the NEXT layer's
+//                     offset / logit projection) in one kernel: 128 -> 128 -> 512 -> 128 (-> 48); the 512-wide hidden
+//                     activations never leave the registers.
+//
+// Five launches per frame instead of ~18.
+//
+// Mapping (the transposed chain of point_head.hip / conv_wino.hip on v_mfma_f32_16x16x4_f32): C = W * X with the output
+// channel on the MFMA row and the TOKEN on the column.  A wave owns 16 tokens; lane (q = lane >> 4, n = lane & 15) holds
+// channels 16 t + 4 q + r (r = 0..3: one float4 of the token's row) of token n for every 16-channel tile t -- which is at
+// the same time (a) what a 16-byte row load delivers, (b) the B operand of the four MFMAs (r) that consume tile t and (c)
+// the accumulator layout of a 16-channel OUTPUT tile, so a layer's result tiles feed the next layer with no lane movement
+// and no LDS.  16 384 tokens = 1 024 waves of 16: one wave per SIMD of the chip, 256 blocks of four waves.
+//
+// Weights.  A "pair" P(o, t) = the 16 x 16 block W[16 o .. +16][16 t .. +16] as 64 lanes x float4 (lane (q, m) holds
+// W[16 o + m][16 t + 4 q + 0..3]): one ds_read_b128 per lane feeds 4 MFMAs (128 matrix cycles).  The host packs each
+// layer's weights as the STREAM of pairs in the order the kernel consumes them (ops.tfusion_prepare), cut into slots of 8
+// pairs (8 KB): output_proj o = 0..7 (slot = the 8 k-tiles of an output tile), then for each 16-wide hidden tile j the
+// linear1 slot (its 8 k-tiles) followed by the linear2 slot (hidden tile j as the k-tile of the 8 output tiles), then the
+// next layer's query projection.  All four waves of a block consume the same stream in lock step: slot s + 1 is read from
+// LDS into registers while the 32 MFMAs of slot s run from registers; slot s + 2 is written to LDS from registers that
+// were loaded from global memory two slots earlier.  Two LDS buffers, one barrier per slot (32 MFMAs = 1 024 matrix
+// cycles).  600 KB of weights per layer stream once per block: 8 B/clk/CU from L2, 32 B/clk/CU from LDS.
+//
+// Arithmetic: plain fp32 (exact products, fp32 accumulation in k order per tile), LayerNorm two-pass (mean, then centred
+// variance; biased; eps inside the root) like torch's.  Against the float64 formulation: <= 2e-6 of the output range
+// (tests/test_gpu_ops.py::test_tfusion_*).
+#include "conv_common.h"
+
+namespace smos {
+
+typedef float tf4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTfC = 128;              // model width (d_model)
+constexpr int kTfT = kTfC / 16;        // k-tiles / output tiles of a 128-wide layer
+constexpr int kTfSlot = 8 * 64;        // float4 per slot: 8 pairs x 64 lanes
+constexpr int kTfSlotBytes = kTfSlot * 16;
+
+// ---- the weight stream: global -> registers (two slots in flight) -> LDS (two buffers) -> fragment registers ----
+struct TfStream {
+  __amdgpu_buffer_rsrc_t srd;
+  unsigned next;        // byte offset of the next slot to request (this thread's first float4 of it)
+  u32x4 g[2][2];        // staging registers: set = slot parity
+};
+
+#define TF_GLOAD(st, set)                                                                        \
+  do {                                                                                           \
+    (st).g[set][0] = __builtin_amdgcn_raw_buffer_load_b128((st).srd, (st).next, 0, 0);           \
+    (st).g[set][1] = __builtin_amdgcn_raw_buffer_load_b128((st).srd, (st).next + 4096u, 0, 0);   \
+    (st).next += (unsigned)kTfSlotBytes;                                                         \
+  } while (0)
+#define TF_PARK(st, set, buf)                                                                    \
+  do {                                                                                           \
+    float4* d_ = (buf) + threadIdx.x;                                                            \
+    d_[0] = make_float4(__uint_as_float((st).g[set][0].x), __uint_as_float((st).g[set][0].y),    \
+                        __uint_as_float((st).g[set][0].z), __uint_as_float((st).g[set][0].w));   \
+    d_[256] = make_float4(__uint_as_float((st).g[set][1].x), __uint_as_float((st).g[set][1].y),  \
+                          __uint_as_float((st).g[set][1].z), __uint_as_float((st).g[set][1].w)); \
+  } while (0)
+
+// One slot: barrier (slot s + 1 visible, everybody done with the buffer slot s + 2 goes to), then per pair p: read pair p
+// of slot s + 1 into the other fragment set and run the four MFMAs of pair p of slot s (PAIR(p) names accumulator and B
+// tile); then park slot s + 2 and request slot s + 4.  PAR = s & 1 (compile-time).
+#define TF_MFMA4(accv, frag, bt)                                                                 \
+  do {                                                                                           \
+    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).x, (bt)[0], accv, 0, 0, 0);               \
+    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).y, (bt)[1], accv, 0, 0, 0);               \
+    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).z, (bt)[2], accv, 0, 0, 0);               \
+    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).w, (bt)[3], accv, 0, 0, 0);               \
+  } while (0)
+#define TF_SLOT(PAR, ACC_OF, B_OF)                                                               \
+  do {                                                                                           \
+    ring_barrier();                                                                              \
+    const float4* rd_ = ring + ((PAR) ^ 1) * kTfSlot + lane;                                     \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                           \
+      frag[(PAR) ^ 1][p_] = rd_[p_ * 64];                                                        \
+      TF_MFMA4(ACC_OF(p_), frag[PAR][p_], B_OF(p_));                                             \
+    }                                                                                            \
+    TF_PARK(st, PAR, ring + (PAR) * kTfSlot);                                                    \
+    TF_GLOAD(st, PAR);                                                                           \
+  } while (0)
+
+// prologue of a stream: slots 0 and 1 parked, slots 2 and 3 in flight, fragments of slot 0 in frag[0]
+#define TF_STREAM_BEGIN(wptr, wbytes)                                                            \
+  do {                                                                                           \
+    st.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wptr), 0, (int)(wbytes), 0x00020000); \
+    st.next = threadIdx.x * 16u;                                                                 \
+    TF_GLOAD(st, 0);                                                                             \
+    TF_GLOAD(st, 1);                                                                             \
+    TF_PARK(st, 0, ring);                                                                        \
+    TF_GLOAD(st, 0);                                                                             \
+    TF_PARK(st, 1, ring + kTfSlot);                                                              \
+    TF_GLOAD(st, 1);                                                                             \
+    ring_barrier();                                                                              \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) frag[0][p_] = ring[p_ * 64 + lane];         \
+  } while (0)
+
+// sum over the four lanes that hold one token (n, n + 16, n + 32, n + 48)
+__device__ __forceinline__ float token_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// LayerNorm over the 128 channels of each token, in place on the B-operand tiles; gamma / beta: per lane the float4 at
+// channel 16 t + 4 q of tile t (LDS)
+__device__ __forceinline__ void layer_norm_tiles(tf4 (&x)[kTfT], const float* gamma, const float* beta, int q, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+  const float mean = token_sum(s) * (1.0f / kTfC);
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) {
+    x[t] -= mean;
+    v += (x[t][0] * x[t][0] + x[t][1] * x[t][1]) + (x[t][2] * x[t][2] + x[t][3] * x[t][3]);
+  }
+  const float rstd = 1.0f / sqrtf(token_sum(v) * (1.0f / kTfC) + eps);
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 16 * t + 4 * q);
+    const float4 b = *reinterpret_cast<const float4*>(beta + 16 * t + 4 * q);
+    x[t][0] = x[t][0] * rstd * g.x + b.x;
+    x[t][1] = x[t][1] * rstd * g.y + b.y;
+    x[t][2] = x[t][2] * rstd * g.z + b.z;
+    x[t][3] = x[t][3] * rstd * g.w + b.w;
+  }
+}
+
+__device__ __forceinline__ tf4 as_tf4(u32x4 v) {
+  return tf4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ u32x4 as_u32x4(tf4 v) {
+  return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tfusion_layer
+// ------------------------------------------------------------------------------------------------------------------
+// params (floats): bo[128] g1[128] be1[128] b1[F] b2[128] g2[128] be2[128] bq[64 (48 used)]
+struct TfLayerArgs {
+  const float* sampled;    // [tokens, 128] sampler output (pitch 128)
+  const float* query;      // [tokens, *] pitch qp_in
+  const float4* wstream;   // ops.tfusion_prepare: 8 + 2 * F / 16 + (has_next ? 4 : 0) slots
+  const float* params;
+  float* out;              // [tokens, *] pitch op: the layer's output query
+  float* qp_next;          // [tokens, 48] or null
+  int64_t q_pitch, o_pitch;
+  int tokens, ffn_tiles, nq;   // F / 16; channels of the next projection (<= 64)
+  int w_bytes;
+  float eps1, eps2;
+};
+
+__global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4* ring = reinterpret_cast<float4*>(lds);                 // 2 x 8 KB
+  float* prm = lds + 2 * kTfSlot * 4;                            // parameters
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, n = lane & 15;
+  const int F = a.ffn_tiles * 16;
+  const int n_prm = 7 * kTfC + F + 64;
+  for (int i = threadIdx.x; i < n_prm; i += 256) prm[i] = a.params[i];
+  const float* p_bo = prm;
+  const float* p_g1 = prm + kTfC;
+  const float* p_be1 = prm + 2 * kTfC;
+  const float* p_b1 = prm + 3 * kTfC;
+  const float* p_b2 = p_b1 + F;
+  const float* p_g2 = p_b2 + kTfC;
+  const float* p_be2 = p_g2 + kTfC;
+  const float* p_bq = p_be2 + kTfC;
+
+  const int row = (int)blockIdx.x * 64 + wave * 16 + n;
+  const bool live = row < a.tokens;
+  const __amdgpu_buffer_rsrc_t ssrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sampled), 0, a.tokens * kTfC * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t qsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.query), 0, (int)(a.tokens * a.q_pitch * 4), 0x00020000);
+  const unsigned s_off = live ? (unsigned)(row * kTfC + 4 * q) * 4u : 0x80000000u;
+  const unsigned q_off = live ? (unsigned)(row * (int)a.q_pitch + 4 * q) * 4u : 0x80000000u;
+
+  tf4 xs[kTfT], xq[kTfT];                 // B tiles: sampled (then q1), query
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) xs[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(ssrd, s_off + 64u * t, 0, 0));
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) xq[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(qsrd, q_off + 64u * t, 0, 0));
+
+  TfStream st;
+  float4 frag[2][8];
+  TF_STREAM_BEGIN(a.wstream, a.w_bytes);           // its barrier also publishes prm
+
+  // ---- output_proj: acc1[o] = sum_t P(o, t) xs[t] ----
+  tf4 acc1[kTfT];
+#pragma unroll
+  for (int o = 0; o < kTfT; ++o) acc1[o] = tf4{0.f, 0.f, 0.f, 0.f};
+#define TF_ACC_OA(p) acc1[o_]
+#define TF_ACC_OB(p) acc1[o_ + 1]
+#define TF_B_T(p) xs[p]
+#pragma unroll
+  for (int o_ = 0; o_ < kTfT; o_ += 2) {
+    TF_SLOT(0, TF_ACC_OA, TF_B_T);
+    TF_SLOT(1, TF_ACC_OB, TF_B_T);
+  }
+#undef TF_ACC_OA
+#undef TF_ACC_OB
+  // + bias + query -> LayerNorm 1 -> q1 (kept in xs: linear1's B operand and the second residual)
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) {
+    const float4 b = *reinterpret_cast<const float4*>(p_bo + 16 * t + 4 * q);
+    xs[t][0] = (acc1[t][0] + b.x) + xq[t][0];
+    xs[t][1] = (acc1[t][1] + b.y) + xq[t][1];
+    xs[t][2] = (acc1[t][2] + b.z) + xq[t][2];
+    xs[t][3] = (acc1[t][3] + b.w) + xq[t][3];
+  }
+  layer_norm_tiles(xs, p_g1, p_be1, q, a.eps1);
+
+  // ---- FFN: per hidden tile j: h = relu(W1[j] q1 + b1[j]) (8 pairs, one accumulator), acc2[o] += W2[o][j] h (8 pairs) ----
+  tf4 acc2[kTfT];
+#pragma unroll
+  for (int o = 0; o < kTfT; ++o) acc2[o] = tf4{0.f, 0.f, 0.f, 0.f};
+  tf4 hacc, hb[1];
+#define TF_ACC_H(p) hacc
+#define TF_ACC_2(p) acc2[p]
+#define TF_B_H(p) hb[0]
+#pragma unroll 1
+  for (int j = 0; j < a.ffn_tiles; ++j) {
+    hacc = tf4{0.f, 0.f, 0.f, 0.f};
+    TF_SLOT(0, TF_ACC_H, TF_B_T);
+    const float4 b = *reinterpret_cast<const float4*>(p_b1 + 16 * j + 4 * q);
+    hb[0][0] = fmaxf(hacc[0] + b.x, 0.f);
+    hb[0][1] = fmaxf(hacc[1] + b.y, 0.f);
+    hb[0][2] = fmaxf(hacc[2] + b.z, 0.f);
+    hb[0][3] = fmaxf(hacc[3] + b.w, 0.f);
+    TF_SLOT(1, TF_ACC_2, TF_B_H);
+  }
+#undef TF_ACC_H
+#undef TF_ACC_2
+#undef TF_B_H
+  // + bias + q1 -> LayerNorm 2 -> the layer's output
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) {
+    const float4 b = *reinterpret_cast<const float4*>(p_b2 + 16 * t + 4 * q);
+    xs[t][0] = (acc2[t][0] + b.x) + xs[t][0];
+    xs[t][1] = (acc2[t][1] + b.y) + xs[t][1];
+    xs[t][2] = (acc2[t][2] + b.z) + xs[t][2];
+    xs[t][3] = (acc2[t][3] + b.w) + xs[t][3];
+  }
+  layer_norm_tiles(xs, p_g2, p_be2, q, a.eps2);
+  {
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(a.tokens * a.o_pitch * 4), 0x00020000);
+    const unsigned o_off = live ? (unsigned)(row * (int)a.o_pitch + 4 * q) * 4u : 0x80000000u;
+#pragma unroll
+    for (int t = 0; t < kTfT; ++t) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(xs[t]), osrd, o_off + 64u * t, 0, 0);
+  }
+
+  // ---- the next layer's offset / logit projection on the fresh output (4 slots: up to 64 channels, nq stored) ----
+  if (a.qp_next) {
+    tf4 accq[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) accq[o] = tf4{0.f, 0.f, 0.f, 0.f};
+#define TF_ACC_Q0(p) accq[0]
+#define TF_ACC_Q1(p) accq[1]
+#define TF_ACC_Q2(p) accq[2]
+#define TF_ACC_Q3(p) accq[3]
+    TF_SLOT(0, TF_ACC_Q0, TF_B_T);
+    TF_SLOT(1, TF_ACC_Q1, TF_B_T);
+    TF_SLOT(0, TF_ACC_Q2, TF_B_T);
+    TF_SLOT(1, TF_ACC_Q3, TF_B_T);
+#undef TF_ACC_Q0
+#undef TF_ACC_Q1
+#undef TF_ACC_Q2
+#undef TF_ACC_Q3
+    const __amdgpu_buffer_rsrc_t nsrd = __builtin_amdgcn_make_buffer_rsrc(a.qp_next, 0, a.tokens * a.nq * 4, 0x00020000);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float4 b = *reinterpret_cast<const float4*>(p_bq + 16 * o + 4 * q);
+      const tf4 v = {accq[o][0] + b.x, accq[o][1] + b.y, accq[o][2] + b.z, accq[o][3] + b.w};
+      const unsigned off = (live && 16 * o + 4 * q < a.nq) ? (unsigned)(row * a.nq + 16 * o + 4 * q) * 4u : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(v), nsrd, off, 0, 0);
+    }
+  }
+#undef TF_B_T
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tfusion_project: up to four independent token-wise Linear jobs (128 -> 16 * tiles) in one launch, blockIdx.y = job
+// ------------------------------------------------------------------------------------------------------------------
+struct TfJob {
+  const float* x;          // [tokens, *] pitch xp
+  const float4* wstream;   // tiles_padded slots (tiles rounded up to even): slot o = P(o, t = 0..7)
+  const float* bias;       // [cout]
+  float* out;              // [tokens, cout] dense rows
+  int64_t xp;
+  int cout, tiles;         // channels stored; slots streamed (even)
+};
+struct TfProjectArgs {
+  TfJob job[4];
+  int tokens;
+};
+
+__global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4* ring = reinterpret_cast<float4*>(lds);
+  const TfJob& jb = a.job[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, n = lane & 15;
+  const int row = (int)blockIdx.x * 64 + wave * 16 + n;
+  const bool live = row < a.tokens;
+  const __amdgpu_buffer_rsrc_t xsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.x), 0, (int)(a.tokens * jb.xp * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(jb.out, 0, a.tokens * jb.cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.bias), 0, jb.cout * 4, 0x00020000);
+  const unsigned x_off = live ? (unsigned)(row * (int)jb.xp + 4 * q) * 4u : 0x80000000u;
+  tf4 xs[kTfT];
+#pragma unroll
+  for (int t = 0; t < kTfT; ++t) xs[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(xsrd, x_off + 64u * t, 0, 0));
+  TfStream st;
+  float4 frag[2][8];
+  TF_STREAM_BEGIN(jb.wstream, jb.tiles * kTfSlotBytes);
+  tf4 acc;
+#define TF_ACC_P(p) acc
+#define TF_B_T(p) xs[p]
+#define TF_EMIT(o)                                                                                                     \
+  do {                                                                                                                 \
+    const tf4 b_ = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(bsrd, (unsigned)(16 * (o) + 4 * q) * 4u, 0, 0));       \
+    const unsigned off_ = (live && 16 * (o) + 4 * q < jb.cout) ? (unsigned)(row * jb.cout + 16 * (o) + 4 * q) * 4u : 0x80000000u; \
+    __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc + b_), osrd, off_, 0, 0);                                      \
+  } while (0)
+#pragma unroll 1
+  for (int o = 0; o < jb.tiles; o += 2) {
+    acc = tf4{0.f, 0.f, 0.f, 0.f};
+    TF_SLOT(0, TF_ACC_P, TF_B_T);
+    TF_EMIT(o);
+    acc = tf4{0.f, 0.f, 0.f, 0.f};
+    TF_SLOT(1, TF_ACC_P, TF_B_T);
+    TF_EMIT(o + 1);
+  }
+#undef TF_ACC_P
+#undef TF_B_T
+#undef TF_EMIT
+}
+
+}  // namespace smos
+
+using namespace smos;
+
+// Token-wise Linear layers y = W x + b on 128-channel token rows, up to four jobs in one launch (the projections of a frame's
+// temporal fusion that do not depend on a previous layer: value_proj of every DeformAttnLayer and the first layer's
+// [sampling_offsets | attention_weights], deformattn/modules/ms_deform_attn.py:94-103).  Per job: x [tokens, *] (row pitch
+// x_pitch floats, >= 128), wstream = ops.tfusion_pack_linear(W) (cout rounded up to a multiple of 32, zero padded), bias
+// [cout], out [tokens, cout] dense.  cout a multiple of 4, <= 256.
+extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const int64_t* x_pitch, const float* const* wstream,
+                                    const float* const* bias, float* const* out, const int64_t* cout, int64_t tokens,
+                                    smos_stream_t stream) {
+  SMOS_REQUIRE(n_jobs >= 1 && n_jobs <= 4 && tokens > 0 && tokens < (1LL << 22), "tfusion_project: 1..4 jobs, tokens < 2^22");
+  TfProjectArgs a;
+  a.tokens = (int)tokens;
+  for (int j = 0; j < n_jobs; ++j) {
+    SMOS_REQUIRE(x[j] && wstream[j] && bias[j] && out[j] && x_pitch[j] >= kTfC && x_pitch[j] % 4 == 0 && cout[j] > 0 &&
+                     cout[j] % 4 == 0 && cout[j] <= 256, "tfusion_project: bad job (pitch >= 128, cout multiple of 4 and <= 256)");
+    SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x[j]) | reinterpret_cast<uintptr_t>(wstream[j]) | reinterpret_cast<uintptr_t>(bias[j]) |
+                   reinterpret_cast<uintptr_t>(out[j])) & 15) == 0, "tfusion_project: pointers must be 16-byte aligned");
+    SMOS_REQUIRE(tokens * x_pitch[j] * 4 < (1LL << 31), "tfusion_project: input larger than 2 GiB");
+    a.job[j].x = x[j]; a.job[j].wstream = reinterpret_cast<const float4*>(wstream[j]); a.job[j].bias = bias[j]; a.job[j].out = out[j];
+    a.job[j].xp = x_pitch[j]; a.job[j].cout = (int)cout[j]; a.job[j].tiles = (int)((cout[j] + 31) / 32 * 2);
+  }
+  for (int j = n_jobs; j < 4; ++j) a.job[j] = a.job[0];
+  const size_t lds = (size_t)2 * kTfSlotBytes;
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_project), lds, 0, &ks, "tfusion_project")) return rc;
+  hipLaunchKernelGGL(tfusion_project, dim3((unsigned)((tokens + 63) / 64), (unsigned)n_jobs), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("tfusion_project");
+}
+
+extern "C" int64_t smos_tfusion_layer_param_floats(int64_t ffn) { return 7 * kTfC + ffn + 64; }
+extern "C" int64_t smos_tfusion_layer_stream_floats(int64_t ffn, int32_t has_next) {
+  return (int64_t)(8 + 2 * (ffn / 16) + (has_next ? 4 : 0)) * kTfSlot * 4;
+}
+
+// One DeformAttnLayer behind its sampler (multi_view_encoder.py:314-320): out = norm2(q1 + linear2(relu(linear1(q1)))) with
+// q1 = norm1(query + output_proj(sampled)); optionally also qp_next = [sampling_offsets | attention_weights](out) of the
+// NEXT layer (nq channels, <= 64).  sampled [tokens, 128] dense, query [tokens, *] pitch q_pitch, out pitch o_pitch;
+// wstream / params = ops.tfusion_prepare(...); d_model 128, ffn a multiple of 16.
+extern "C" int smos_tfusion_layer(const float* sampled, const float* query, int64_t q_pitch, const float* wstream, const float* params,
+                                  float* out, int64_t o_pitch, float* qp_next, int64_t nq, int64_t tokens, int64_t ffn, float eps1,
+                                  float eps2, smos_stream_t stream) {
+  SMOS_REQUIRE(tokens > 0 && tokens < (1LL << 22) && ffn >= 16 && ffn % 16 == 0 && ffn <= 4096, "tfusion_layer: bad sizes");
+  SMOS_REQUIRE(sampled && query && wstream && params && out && q_pitch >= kTfC && o_pitch >= kTfC && q_pitch % 4 == 0 &&
+                   o_pitch % 4 == 0, "tfusion_layer: null pointer / bad pitch");
+  SMOS_REQUIRE(!qp_next || (nq > 0 && nq <= 64 && nq % 4 == 0), "tfusion_layer: the next projection has 4..64 channels");
+  SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(sampled) | reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(wstream) |
+                 reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(qp_next)) & 15) == 0,
+               "tfusion_layer: pointers must be 16-byte aligned");
+  SMOS_REQUIRE(tokens * q_pitch * 4 < (1LL << 31) && tokens * o_pitch * 4 < (1LL << 31), "tfusion_layer: a tensor larger than 2 GiB");
+  TfLayerArgs a;
+  a.sampled = sampled; a.query = query; a.wstream = reinterpret_cast<const float4*>(wstream); a.params = params; a.out = out;
+  a.qp_next = qp_next; a.q_pitch = q_pitch; a.o_pitch = o_pitch; a.tokens = (int)tokens; a.ffn_tiles = (int)(ffn / 16);
+  a.nq = (int)nq; a.eps1 = eps1; a.eps2 = eps2;
+  a.w_bytes = (int)(smos_tfusion_layer_stream_floats(ffn, qp_next != nullptr) * 4);
+  const size_t lds = (size_t)2 * kTfSlotBytes + (size_t)smos_tfusion_layer_param_floats(ffn) * sizeof(float);
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_layer), lds, 0, &ks, "tfusion_layer")) return rc;
+  hipLaunchKernelGGL(tfusion_layer, dim3((unsigned)((tokens + 63) / 64)), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("tfusion_layer");
+}

@@ -95,6 +95,21 @@ class InferenceEngine:
                 lin2=(lyr.linear2.weight.detach(), lyr.linear2.bias.detach()),
                 norm2=(lyr.norm2.weight.detach(), lyr.norm2.bias.detach(), lyr.norm2.eps)))
 
+        # temporal fusion on the own MFMA kernels (csrc/tfusion.hip): value_proj of every layer + the first layer's offset /
+        # logit projection as ONE launch, then per layer the sampler and ONE kernel for output_proj -> +query -> LayerNorm ->
+        # FFN -> + -> LayerNorm (-> the next layer's projection).  SMOS_TFUSION=0: the library-GEMM form (A/B switch).
+        self.tfusion = os.environ.get("SMOS_TFUSION", "1") != "0"
+        self._tf_ok = False
+        try:
+            for i, L in enumerate(self.layers):
+                nxt = self.layers[i + 1].qproj if i + 1 < len(self.layers) else None
+                L.tf = ops.TfusionLayer(L.out, L.norm1, L.lin1, L.lin2, L.norm2, next_qproj=nxt)
+                L.wv_stream = ops.tfusion_pack_linear(L.value[0])
+                L.wq_stream = ops.tfusion_pack_linear(L.qproj[0]) if i == 0 else None
+            self._tf_ok = all(L.value[0].shape[0] // L.heads == 32 and L.points <= 8 and L.qproj[0].shape[0] % 4 == 0 for L in self.layers)
+        except RuntimeError:
+            self._tf_ok = False
+
         self.conv_1 = _fold(enc.conv_1.conv.weight, None, enc.conv_1.bn)
         self.conv_2 = _fold(enc.conv_2.conv.weight, None, enc.conv_2.bn)
         # the three 1x1 aux heads as ONE block-diagonal 1x1 conv over the 320-channel decoder input
@@ -309,6 +324,18 @@ class InferenceEngine:
         else:
             query = memory.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
         lq = hh * ww
+        if self.tfusion and self._tf_ok and channels_last and c == 128:
+            # five launches: projections | (sampler, layer) x 2
+            query = query if query.is_contiguous() else query.contiguous()
+            jobs = [(src, L.wv_stream, L.value[1]) for L in self.layers] + [(query, self.layers[0].wq_stream, self.layers[0].qproj[1])]
+            outs = []
+            for k in range(0, len(jobs), 4):
+                outs += ops.tfusion_project(jobs[k:k + 4])
+            qp = outs[-1]
+            for i, L in enumerate(self.layers):
+                sampled = ops.msda_fwd_qp(outs[i].view(b, lq, L.heads, 32), qp.view(b, lq, -1), hh, ww, L.points)
+                query, qp = ops.tfusion_layer(sampled, query, L.tf)
+            return query.view(b, hh, ww, c).permute(0, 3, 1, 2)
         for L in self.layers:
             h, p = L.heads, L.points
             value = F.linear(src, *L.value).view(b, lq, h, c // h)

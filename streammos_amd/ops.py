@@ -740,6 +740,133 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# temporal fusion (csrc/tfusion.hip): the token-wise Linear / LayerNorm / FFN chain of a DeformAttnLayer on the matrix cores
+# ---------------------------------------------------------------------------------------------
+def _tf_pairs(w):
+    """w [O, K] (O, K multiples of 16) -> [O/16, K/16, 64, 4]: pair (o, t) = 64 lanes x float4, lane q * 16 + m holding
+    w[16 o + m][16 t + 4 q + 0..3] -- the A operands of the four v_mfma_f32_16x16x4_f32 that multiply k-tile t into output tile o."""
+    o, k = w.shape
+    v = w.float().reshape(o // 16, 16, k // 16, 4, 4)          # [o, m, t, q, r]
+    return v.permute(0, 2, 3, 1, 4).reshape(o // 16, k // 16, 64, 4)
+
+
+def tfusion_pack_linear(w):
+    """w [cout, 128] -> the weight stream of one smos_tfusion_project job: cout zero-padded to a multiple of 32, slot o = the
+    eight pairs (o, t = 0..7)."""
+    cout, k = w.shape
+    if k != 128 or cout > 256:
+        raise RuntimeError("tfusion_pack_linear: expected [<=256, 128], got %s" % (tuple(w.shape),))
+    pad = (cout + 31) // 32 * 32
+    wp = torch.zeros((pad, k), dtype=torch.float32, device=w.device)
+    wp[:cout] = w
+    return _tf_pairs(wp).reshape(-1).contiguous()
+
+
+class TfusionLayer:
+    """Weights of one DeformAttnLayer behind its sampler in the order smos_tfusion_layer streams them, plus (optionally) the
+    NEXT layer's [sampling_offsets | attention_weights] projection, which the kernel applies to its fresh output."""
+
+    def __init__(self, out, norm1, lin1, lin2, norm2, next_qproj=None):
+        wo, bo = out
+        w1, b1 = lin1
+        w2, b2 = lin2
+        ffn = w1.shape[0]
+        if tuple(wo.shape) != (128, 128) or w1.shape[1] != 128 or tuple(w2.shape) != (128, ffn) or ffn % 16:
+            raise RuntimeError("TfusionLayer: built for d_model 128 and an FFN width that is a multiple of 16")
+        dev = wo.device
+        po, p1, p2 = _tf_pairs(wo), _tf_pairs(w1), _tf_pairs(w2)          # [8,8,..], [F/16,8,..], [8,F/16,..]
+        slots = [po.reshape(8, 8, 64, 4)]
+        ffn_slots = torch.stack((p1, p2.permute(1, 0, 2, 3)), 1)            # [F/16, 2, 8 pairs, 64, 4]: linear1 slot, linear2 slot
+        slots.append(ffn_slots.reshape(-1, 8, 64, 4))
+        self.nq = 0
+        bq = torch.zeros(64, dtype=torch.float32, device=dev)
+        if next_qproj is not None:
+            wq, bqv = next_qproj
+            self.nq = int(wq.shape[0])
+            if self.nq > 64 or self.nq % 4 or wq.shape[1] != 128:
+                raise RuntimeError("TfusionLayer: the next projection must have 4..64 output channels (multiple of 4)")
+            wqp = torch.zeros((64, 128), dtype=torch.float32, device=dev)
+            wqp[:self.nq] = wq
+            bq[:self.nq] = bqv
+            slots.append(_tf_pairs(wqp).reshape(4, 8, 64, 4))
+        self.stream = torch.cat(slots).reshape(-1).contiguous()
+        self.params = torch.cat([bo.float(), norm1[0].float(), norm1[1].float(), b1.float(), b2.float(), norm2[0].float(),
+                                 norm2[1].float(), bq]).contiguous()
+        self.ffn = int(ffn)
+        self.eps1 = float(norm1[2]) if len(norm1) > 2 else 1e-5
+        self.eps2 = float(norm2[2]) if len(norm2) > 2 else 1e-5
+        lib = _lib.load()
+        if (self.stream.numel() != int(lib.smos_tfusion_layer_stream_floats(self.ffn, 1 if self.nq else 0)) or
+                self.params.numel() != int(lib.smos_tfusion_layer_param_floats(self.ffn))):
+            raise RuntimeError("TfusionLayer: packed sizes disagree with the kernel's")
+
+
+def _token_rows(name, t):
+    """(tokens, pitch) of a token matrix [..., C] with contiguous channels and evenly pitched rows."""
+    c = t.shape[-1]
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        raise RuntimeError("%s: float32 rows with contiguous channels expected" % name)
+    rows = t.reshape(-1, c) if t.is_contiguous() else t
+    if rows.dim() != 2:
+        raise RuntimeError("%s: a dense [..., C] tensor or a pitched [tokens, C] view expected, got %s / %s" % (name, tuple(t.shape), t.stride()))
+    return rows.shape[0], rows.stride(0)
+
+
+def tfusion_project(jobs):
+    """jobs: up to four (x [..., 128] token rows, wstream = tfusion_pack_linear(W), bias [cout]) -> list of [tokens, cout]
+    outputs, ONE launch (csrc/tfusion.hip): the fusion's projections that depend on no previous layer."""
+    n = len(jobs)
+    if not 1 <= n <= 4:
+        raise RuntimeError("tfusion_project: 1..4 jobs")
+    xs, pit, ws, bs, outs, couts = ((ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(),
+                                    (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)())
+    res = []
+    tokens = None
+    for j, (x, w, b) in enumerate(jobs):
+        _require_cuda("tfusion_project", x, w, b)
+        tk, pitch = _token_rows("tfusion_project", x)
+        if x.shape[-1] != 128 or (tokens is not None and tk != tokens):
+            raise RuntimeError("tfusion_project: every job reads the same number of 128-channel token rows")
+        tokens = tk
+        cout = int(b.shape[0])
+        if w.numel() != (cout + 31) // 32 * 32 * 128:
+            raise RuntimeError("tfusion_project: weight stream of %d floats for %d outputs" % (w.numel(), cout))
+        out = torch.empty((tokens, cout), dtype=torch.float32, device=x.device)
+        res.append(out)
+        xs[j], pit[j], ws[j], bs[j], outs[j], couts[j] = x.data_ptr(), pitch, w.data_ptr(), b.data_ptr(), out.data_ptr(), cout
+    lib = _lib.load()
+    x0 = jobs[0][0]
+    with _on(x0.device), profiling.span("tfusion_project[%dx128->%s]" % (tokens, "+".join(str(int(c)) for c in couts))):
+        rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, couts, tokens, _stream(x0))
+    _lib.check(rc, "smos_tfusion_project")
+    return res
+
+
+def tfusion_layer(sampled, query, prep, out=None):
+    """One DeformAttnLayer behind its sampler (multi_view_encoder.py:314-320) in one launch: norm2(q1 + FFN(q1)) with q1 =
+    norm1(query + output_proj(sampled)); returns (out [tokens, 128], qp_next [tokens, nq] or None).  sampled: dense
+    [..., 128]; query: token rows (may be pitched); prep: TfusionLayer."""
+    _require_cuda("tfusion_layer", sampled, query, out)
+    tokens, sp = _token_rows("tfusion_layer", sampled)
+    tq, qp = _token_rows("tfusion_layer", query)
+    if sp != 128 or tq != tokens or sampled.shape[-1] != 128 or query.shape[-1] != 128:
+        raise RuntimeError("tfusion_layer: sampled must be dense [tokens, 128] and query hold as many 128-channel rows")
+    if out is None:
+        out = torch.empty((tokens, 128), dtype=torch.float32, device=sampled.device)
+    to, op = _token_rows("tfusion_layer", out)
+    if to != tokens or out.shape[-1] != 128:
+        raise RuntimeError("tfusion_layer: out must hold [tokens, 128]")
+    nxt = torch.empty((tokens, prep.nq), dtype=torch.float32, device=sampled.device) if prep.nq else None
+    lib = _lib.load()
+    with _on(sampled.device), profiling.span("tfusion_layer[%dx128x%d%s]" % (tokens, prep.ffn, "+q%d" % prep.nq if prep.nq else "")):
+        rc = lib.smos_tfusion_layer(sampled.data_ptr(), query.data_ptr(), qp, prep.stream.data_ptr(), prep.params.data_ptr(),
+                                    out.data_ptr(), op, nxt.data_ptr() if nxt is not None else None, prep.nq, tokens, prep.ffn,
+                                    prep.eps1, prep.eps2, _stream(sampled))
+    _lib.check(rc, "smos_tfusion_layer")
+    return out, nxt
+
+
 class TapWeights:
     """The per-tap matrices of a 3x3 convolution's input channels [c0, c1) in the forms upconv3x3 uses.  Everything
     derived from the weights lives in this object (owned by the engine that folded them) -- never in a cache keyed by

@@ -1079,3 +1079,70 @@ def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb)
     g = torch.sigmoid(F.linear(F.relu(F.linear(z.mean((2, 3)), w1.double(), b1.double())), w2.double(), b2.double()))
     ref = F.relu(z * g[:, :, None, None] + xres.double())
     assert (got.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+def _tf_layer_weights(gen, ffn, nq):
+    def lin(o, i):
+        return ((torch.randn((o, i), generator=gen) / i ** 0.5).to(DEV), (torch.randn(o, generator=gen) * 0.3).to(DEV))
+
+    def norm():
+        return ((1.0 + 0.3 * torch.randn(128, generator=gen)).to(DEV), (0.2 * torch.randn(128, generator=gen)).to(DEV), 1e-5)
+    return {"out": lin(128, 128), "norm1": norm(), "lin1": lin(ffn, 128), "lin2": lin(128, ffn), "norm2": norm(),
+            "next": lin(nq, 128) if nq else None}
+
+
+@pytest.mark.parametrize("tokens,ffn,nq,pitched", [(4 * 64 * 64, 512, 48, False), (777, 512, 48, True), (64, 512, 0, False),
+                                                    (1000, 64, 16, False), (5, 1024, 64, True)])
+def test_tfusion_layer_against_float64(tokens, ffn, nq, pitched):
+    """csrc/tfusion.hip::tfusion_layer -- output_proj, + query, LayerNorm, linear1, ReLU, linear2, +, LayerNorm and the next
+    layer's offset / logit projection in one launch (networks/multi_view_encoder.py:314-320,
+    deformattn/modules/ms_deform_attn.py:94-115) -- against the same chain in float64: ragged token counts (the last block and
+    the last wave partly empty), a pitched query (a channel slice of a wider map), with and without the next projection."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(131)
+    w = _tf_layer_weights(gen, ffn, nq)
+    sampled = torch.randn((tokens, 128), generator=gen).to(DEV)
+    wide = torch.randn((tokens, 160), generator=gen).to(DEV)
+    query = wide[:, 16:144] if pitched else wide[:, 16:144].contiguous()
+    prep = ops.TfusionLayer(w["out"], w["norm1"], w["lin1"], w["lin2"], w["norm2"], next_qproj=w["next"])
+    out, nxt = ops.tfusion_layer(sampled, query, prep)
+    d = lambda t: t.double()
+    q1 = F.layer_norm(d(query) + F.linear(d(sampled), d(w["out"][0]), d(w["out"][1])), (128,), d(w["norm1"][0]), d(w["norm1"][1]), 1e-5)
+    ffn_out = F.linear(F.relu(F.linear(q1, d(w["lin1"][0]), d(w["lin1"][1]))), d(w["lin2"][0]), d(w["lin2"][1]))
+    want = F.layer_norm(q1 + ffn_out, (128,), d(w["norm2"][0]), d(w["norm2"][1]), 1e-5)
+    err = (out.double() - want).abs().max().item() / want.abs().max().item()
+    print("tfusion_layer %d tokens, ffn %d: %.2e of range" % (tokens, ffn, err))
+    assert out.shape == (tokens, 128) and err <= 2e-6, err
+    if nq:
+        want_q = F.linear(want, d(w["next"][0]), d(w["next"][1]))
+        errq = (nxt.double() - want_q).abs().max().item() / want_q.abs().max().item()
+        assert nxt.shape == (tokens, nq) and errq <= 2e-6, errq
+    else:
+        assert nxt is None
+    out2, nxt2 = ops.tfusion_layer(sampled, query, prep)
+    assert torch.equal(out, out2) and (nxt is None or torch.equal(nxt, nxt2))          # fixed order: run-to-run identical
+    # against the unfused chain the engine used before (library GEMMs + add_layer_norm): same function in fp32
+    q1f = ops.add_layer_norm(query.contiguous(), F.linear(sampled, *w["out"]), w["norm1"][0], w["norm1"][1], 1e-5)
+    wantf = ops.add_layer_norm(q1f, F.linear(F.relu(F.linear(q1f, *w["lin1"])), *w["lin2"]), w["norm2"][0], w["norm2"][1], 1e-5)
+    assert (out - wantf).abs().max().item() <= 4e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("tokens", [4 * 64 * 64, 1000, 3])
+def test_tfusion_project_against_float64(tokens):
+    """csrc/tfusion.hip::tfusion_project: the value projections of two layers (one shared input) and an offset / logit
+    projection of 48 channels from another, pitched input as three jobs of one launch, against F.linear in float64."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(137)
+    src = torch.randn((tokens, 128), generator=gen).to(DEV)
+    wide = torch.randn((tokens, 192), generator=gen).to(DEV)
+    query = wide[:, 32:160]
+    ws = [((torch.randn((o, 128), generator=gen) / 128 ** 0.5).to(DEV), torch.randn(o, generator=gen).to(DEV)) for o in (128, 128, 48, 256)]
+    outs = ops.tfusion_project([(src, ops.tfusion_pack_linear(ws[0][0]), ws[0][1]), (src, ops.tfusion_pack_linear(ws[1][0]), ws[1][1]),
+                                (query, ops.tfusion_pack_linear(ws[2][0]), ws[2][1]), (query, ops.tfusion_pack_linear(ws[3][0]), ws[3][1])])
+    for got, x, (w, b) in zip(outs, (src, src, query, query), ws):
+        want = F.linear(x.double(), w.double(), b.double())
+        assert got.shape == want.shape
+        err = (got.double() - want).abs().max().item() / want.abs().max().item()
+        assert err <= 2e-6, err
+    with pytest.raises(RuntimeError):
+        ops.tfusion_project([(src.cpu(), ops.tfusion_pack_linear(ws[0][0]), ws[0][1])])
