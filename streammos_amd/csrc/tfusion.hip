@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, n = lane & 15;
   const int F = a.ffn_tiles * 16;
-  const int n_prm = 7 * kTfC + F + 64;
+  const int n_prm = 6 * kTfC + F + 64;
   for (int i = threadIdx.x; i < n_prm; i += 256) prm[i] = a.params[i];
   const float* p_bo = prm;
   const float* p_g1 = prm + kTfC;
@@ -382,7 +382,7 @@ extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const
   return check_launch("tfusion_project");
 }
 
-extern "C" int64_t smos_tfusion_layer_param_floats(int64_t ffn) { return 7 * kTfC + ffn + 64; }
+extern "C" int64_t smos_tfusion_layer_param_floats(int64_t ffn) { return 6 * kTfC + ffn + 64; }
 extern "C" int64_t smos_tfusion_layer_stream_floats(int64_t ffn, int32_t has_next) {
   return (int64_t)(8 + 2 * (ffn / 16) + (has_next ? 4 : 0)) * kTfSlot * 4;
 }
