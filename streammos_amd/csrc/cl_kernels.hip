@@ -7,6 +7,8 @@
 //
 // A "row" below is the C channels of one pixel / point; every tensor argument carries its own row pitch in
 // elements, so a tensor may be a channel slice of a wider buffer (concatenations are written in place).
+#include <stdlib.h>
+
 #include "smos_common.h"
 
 namespace smos {
@@ -400,6 +402,132 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
   }
 }
 
+
+// The same function with 16-byte lanes (round 4).  A row of C channels is read by C / 4 lanes as float4, so a wave handles
+// G = 256 / C points at once (C = 64: four 16-lane groups; C = 32: eight 8-lane groups); group g walks the C / 4 consecutive
+// points [g * C / 4, (g + 1) * C / 4) of the wave's 64-point run, which keeps the same-cell runs of the azimuth-ordered
+// points together (a run is cut only at the group borders).  Per point the one-lane-per-channel kernel above issued 9 scalar
+// lane reads, their scalar address arithmetic (one scalar unit per CU: the bottleneck) and 4 row loads per wave; here a
+// wave instruction serves G points: 9 LDS-crossbar shuffles, 4 loads, 16 fused multiply-adds and one row store per G points.
+// The value of a point is the same expression (taps in order, absent taps skipped) and the scatter is a maximum, so the
+// results equal the old kernel's bit for bit.  (Requires 16-byte aligned rows: pitches and channel offsets multiples of 4.)
+template <int kC>
+__global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
+  constexpr int kL = kC / 4;            // lanes per row = points per group
+  constexpr int kWavesPerBlock = kBlock / kWave;
+  const int lane = threadIdx.x & 63;
+  const int l = lane % kL, grp = lane / kL;
+  const int runs_per_sample = (a.N + 63) / 64;
+  const int64_t n_runs = (int64_t)a.B * runs_per_sample;
+  for (int64_t run = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); run < n_runs; run += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int b = (int)(run / runs_per_sample);
+    const int n0 = (int)(run - (int64_t)b * runs_per_sample) * 64;
+    const int n = n0 + lane;
+    // ---- phase A: lane j <-> point j (identical to gather_scatter_cl)
+    int off[4] = {-1, -1, -1, -1};
+    float wt[4] = {0.f, 0.f, 0.f, 0.f};
+    int cell = -1;
+    if (n < a.N) {
+      const float* cr = a.gcoord + ((int64_t)b * a.N + n) * a.Kg;
+      const float iy = pix_cl(cr[0], a.gsy, a.Hg), ix = pix_cl(cr[1], a.gsx, a.Wg);
+      const float fy = floorf(iy), fx = floorf(ix);
+      const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+      const bool fin = (iy > -2.0f) && (iy < (float)(a.Hg + 1)) && (ix > -2.0f) && (ix < (float)(a.Wg + 1));
+      const int y0 = fin ? (int)fy : -5, x0 = fin ? (int)fx : -5;
+      const float w4[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = y0 + (k >> 1), xx = x0 + (k & 1);
+        const bool in = (y >= 0) && (y < a.Hg) && (xx >= 0) && (xx < a.Wg);
+        off[k] = in ? y * a.Wg + xx : -1;
+        wt[k] = in ? w4[k] : 0.0f;
+      }
+      if (a.scoord) {
+        const float* sr = a.scoord + ((int64_t)b * a.N + n) * a.Ks;
+        const float py = __fmul_rn(sr[0], a.ssy), px = __fmul_rn(sr[1], a.ssx);
+        const bool ok = (py > -1.0f) && (py < (float)a.Ho) && (px > -1.0f) && (px < (float)a.Wo);
+        cell = ok ? (int)py * a.Wo + (int)px : -1;
+      }
+    }
+    // a run without a tap inside the source map (the padding tail of a scan) gathers zeros: nothing to add to a zero-filled
+    // target, and its point rows are zeros
+    const bool any_tap = __builtin_amdgcn_ballot_w64((off[0] >= 0) | (off[1] >= 0) | (off[2] >= 0) | (off[3] >= 0)) != 0;
+    // ---- phase B: lane = (point group, 4 channels)
+    const float* gb = a.grid + (int64_t)b * a.Hg * a.Wg * a.gp + 4 * l;
+    float* ob = a.out ? a.out + (int64_t)b * a.Ho * a.Wo * a.op + 4 * l : nullptr;
+    float* pb = a.pts_out ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n + 4 * l : nullptr;
+    if (!any_tap) {
+      if (pb) {
+        for (int i = 0; i < kL; ++i) {
+          const int j = grp * kL + i;
+          if (n0 + j < a.N) *reinterpret_cast<float4*>(pb + (int64_t)j * a.po_n) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      continue;
+    }
+    int cur = -1;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {
+      if (cur >= 0) {
+        int* dst = reinterpret_cast<int*>(ob + (int64_t)cur * a.op);
+        if (best.x > 0.0f) atomicMax(dst + 0, __float_as_int(best.x));
+        if (best.y > 0.0f) atomicMax(dst + 1, __float_as_int(best.y));
+        if (best.z > 0.0f) atomicMax(dst + 2, __float_as_int(best.z));
+        if (best.w > 0.0f) atomicMax(dst + 3, __float_as_int(best.w));
+      }
+    };
+    constexpr int kU = 4;
+#pragma unroll 1
+    for (int i0 = 0; i0 < kL; i0 += kU) {
+      float4 g[kU][4];
+      float w[kU][4];
+      int o[kU][4], c[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int src = grp * kL + i0 + u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[u][k] = __shfl(off[k], src);
+          w[u][k] = __shfl(wt[k], src);
+        }
+        c[u] = __shfl(cell, src);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[u][k] = *reinterpret_cast<const float4*>(gb + (int64_t)max(o[u][k], 0) * a.gp);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int j = grp * kL + i0 + u;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool has = o[u][k] >= 0;
+          v.x = has ? v.x + g[u][k].x * w[u][k] : v.x;
+          v.y = has ? v.y + g[u][k].y * w[u][k] : v.y;
+          v.z = has ? v.z + g[u][k].z * w[u][k] : v.z;
+          v.w = has ? v.w + g[u][k].w * w[u][k] : v.w;
+        }
+        if (n0 + j < a.N) {
+          if (pb) *reinterpret_cast<float4*>(pb + (int64_t)j * a.po_n) = v;
+          if (ob) {
+            if (c[u] != cur) {
+              flush();
+              cur = c[u];
+              best = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            best.x = fmaxf(best.x, v.x);
+            best.y = fmaxf(best.y, v.y);
+            best.z = fmaxf(best.z, v.z);
+            best.w = fmaxf(best.w, v.w);
+          }
+        }
+      }
+    }
+    if (ob) flush();
+  }
+}
+
 }  // namespace smos
 
 using namespace smos;
@@ -508,6 +636,24 @@ extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, con
   a.gp = grid_pitch; a.op = out_pitch; a.po_b = po_b; a.po_n = po_n;
   a.B = (int)B; a.N = (int)N; a.Kg = Kg; a.Ks = Ks; a.Hg = (int)Hg; a.Wg = (int)Wg; a.Ho = (int)Ho; a.Wo = (int)Wo;
   a.gsy = gscale[0]; a.gsx = gscale[1]; a.ssy = out ? sscale[0] : 0.f; a.ssx = out ? sscale[1] : 0.f;
+  // 16-byte lanes wherever the rows are 16-byte aligned (every call of the engine); SMOS_GS_VEC=0: the one-lane-per-channel
+  // kernel (A/B, same results)
+  static const bool want_vec = [] {
+    const char* e = getenv("SMOS_GS_VEC");
+    return !(e && e[0] == '0');
+  }();
+  const bool vec = want_vec && al16(grid) && grid_pitch % 4 == 0 && (!out || (al16(out) && out_pitch % 4 == 0)) &&
+                   (!pts_out || (al16(pts_out) && po_n % 4 == 0 && po_b % 4 == 0));
+  if (vec) {
+    const int64_t runs = B * ((N + 63) / 64);
+    const int64_t blocks = (runs + 3) / 4;
+    dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));
+    if (C == 32)
+      hipLaunchKernelGGL((gather_scatter_cl4<32>), g, dim3(kBlock), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((gather_scatter_cl4<64>), g, dim3(kBlock), 0, (hipStream_t)stream, a);
+    return check_launch("gather_scatter_cl");
+  }
   const int64_t runs = B * ((N + C - 1) / C);
   const int64_t blocks = (runs * C + kBlock - 1) / kBlock;
   dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));

@@ -578,6 +578,30 @@ def test_gather_scatter_channels_last_against_unfused_ops(c, hw_g, hw_o, sg, ss)
     assert torch.equal(rows2, rows[:, :, 8:])
 
 
+@pytest.mark.parametrize("c,hw_g,hw_o,scale", [(64, (32, 128), (16, 64), 0.25), (32, (64, 64), (8, 256), 0.5)])
+def test_gather_scatter_cl_float4_lanes_equal_the_one_lane_per_channel_kernel(c, hw_g, hw_o, scale):
+    """csrc/cl_kernels.hip: gather_scatter_cl4 (a row read by C / 4 lanes as float4, 256 / C points per wave instruction; what
+    the engine's 16-byte aligned maps get) against gather_scatter_cl (one lane per channel; what rows that are not 16-byte
+    aligned still get -- selected here by an odd pitch): the same expression per point and a maximum per cell, so the scatter
+    target and the point rows are equal bit for bit.  Ragged point count, padding tail, points outside both maps."""
+    gen = torch.Generator(device="cpu").manual_seed(43)
+    b, n = 3, 64 * 37 + 21
+    grid = _to_cl(torch.relu(torch.randn((b, c) + hw_g, generator=gen)).to(DEV))
+    gcoord = _model_like_coords(gen, b, n, hw_g[0] / scale, hw_g[1] / scale).to(DEV)
+    scoord = _model_like_coords(gen, b, n, hw_o[0] / scale, hw_o[1] / scale).to(DEV)
+    gcoord[:, -300:] = -4864.0
+    scoord[:, -300:] = -4864.0
+    res = []
+    for pad in (0, 1):                                  # pad = 1: rows of C + 1 floats -> not 16-byte aligned -> the scalar-lane kernel
+        tgt_w = torch.zeros((b, hw_o[0], hw_o[1], c + pad), device=DEV)
+        rows_w = torch.full((b, n, c + pad), 5.0, device=DEV)
+        ops.gather_scatter_cl(grid, gcoord, (scale, scale), scoord, (scale, scale), out=tgt_w[..., :c].permute(0, 3, 1, 2),
+                              pts_out=rows_w[:, :, :c])
+        res.append((tgt_w[..., :c].clone(), rows_w[:, :, :c].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][0].abs().max().item() > 0 and bool((res[0][1][:, -300:] == 0).all())
+
+
 @pytest.mark.parametrize("c,hw_g,hw_o,scale", [(64, (16, 512), (128, 128), 0.25), (32, (256, 256), (32, 1024), 0.5)])
 def test_gather_scatter_channels_last_full_size(c, hw_g, hw_o, scale):
     """The engine's cross-view transfers at the validation shape (4 x 160 000 points incl. the padding tail at -1000):
