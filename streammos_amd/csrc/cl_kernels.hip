@@ -403,20 +403,25 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
 }
 
 
-// The same function with 16-byte lanes (round 4).  A row of C channels is read by C / 4 lanes as float4, so a wave handles
-// G = 256 / C points at once (C = 64: four 16-lane groups; C = 32: eight 8-lane groups); group g walks the C / 4 consecutive
-// points [g * C / 4, (g + 1) * C / 4) of the wave's 64-point run, which keeps the same-cell runs of the azimuth-ordered
-// points together (a run is cut only at the group borders).  Per point the one-lane-per-channel kernel above issued 9 scalar
-// lane reads, their scalar address arithmetic (one scalar unit per CU: the bottleneck) and 4 row loads per wave; here a
-// wave instruction serves G points: 9 LDS-crossbar shuffles, 4 loads, 16 fused multiply-adds and one row store per G points.
-// The value of a point is the same expression (taps in order, absent taps skipped) and the scatter is a maximum, so the
-// results equal the old kernel's bit for bit.  (Requires 16-byte aligned rows: pitches and channel offsets multiples of 4.)
-template <int kC>
+// The same function with 16-byte lanes for the GATHER half (round 4).  A row of C channels is read by C / 4 lanes as float4,
+// so a wave instruction serves G = 256 / C points (C = 64: four 16-lane groups; C = 32: eight 8-lane groups); group g walks
+// the C / 4 consecutive points [g * C / 4, (g + 1) * C / 4) of the wave's 64-point run.  Per point the one-lane-per-channel
+// kernel above issues 9 scalar lane reads, their scalar address arithmetic (one scalar unit per CU) and 4 row loads per
+// wave; here a wave instruction serves G points: 9 LDS-crossbar shuffles, 4 loads, 16 multiply-adds, one 16-byte row store.
+// The SCATTER half stays one lane per channel -- a row atomic of 16-byte lanes is four instructions that each touch every
+// fourth word of the row (measured: 2 - 3x slower than the scalar-lane kernel) -- so the gathered rows of the run go through
+// a wave-private LDS tile ([64 points][C], written as float4, read back one word per lane: conflict-free both ways) and a
+// second sweep with lane = channel keeps the running maximum per target cell and flushes it with ONE dense row atomic when
+// the cell changes, exactly as above.  The value of a point is the same expression (taps in order, absent taps skipped)
+// and the scatter is a maximum, so the results equal the old kernel's bit for bit.  (16-byte aligned rows required.)
+template <int kC, bool kScatter>
 __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float gs_lds[];
   constexpr int kL = kC / 4;            // lanes per row = points per group
   constexpr int kWavesPerBlock = kBlock / kWave;
   const int lane = threadIdx.x & 63;
   const int l = lane % kL, grp = lane / kL;
+  float* tile = gs_lds + (kScatter ? (threadIdx.x >> 6) * 64 * kC : 0);      // this wave's [64][kC]
   const int runs_per_sample = (a.N + 63) / 64;
   const int64_t n_runs = (int64_t)a.B * runs_per_sample;
   for (int64_t run = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); run < n_runs; run += (int64_t)gridDim.x * kWavesPerBlock) {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
         off[k] = in ? y * a.Wg + xx : -1;
         wt[k] = in ? w4[k] : 0.0f;
       }
-      if (a.scoord) {
+      if (kScatter) {
         const float* sr = a.scoord + ((int64_t)b * a.N + n) * a.Ks;
         const float py = __fmul_rn(sr[0], a.ssy), px = __fmul_rn(sr[1], a.ssx);
         const bool ok = (py > -1.0f) && (py < (float)a.Ho) && (px > -1.0f) && (px < (float)a.Wo);
@@ -452,9 +457,9 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
     // a run without a tap inside the source map (the padding tail of a scan) gathers zeros: nothing to add to a zero-filled
     // target, and its point rows are zeros
     const bool any_tap = __builtin_amdgcn_ballot_w64((off[0] >= 0) | (off[1] >= 0) | (off[2] >= 0) | (off[3] >= 0)) != 0;
+    const bool any_cell = !kScatter || __builtin_amdgcn_ballot_w64(cell >= 0) != 0;
     // ---- phase B: lane = (point group, 4 channels)
     const float* gb = a.grid + (int64_t)b * a.Hg * a.Wg * a.gp + 4 * l;
-    float* ob = a.out ? a.out + (int64_t)b * a.Ho * a.Wo * a.op + 4 * l : nullptr;
     float* pb = a.pts_out ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n + 4 * l : nullptr;
     if (!any_tap) {
       if (pb) {
@@ -465,23 +470,13 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
       }
       continue;
     }
-    int cur = -1;
-    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto flush = [&]() {
-      if (cur >= 0) {
-        int* dst = reinterpret_cast<int*>(ob + (int64_t)cur * a.op);
-        if (best.x > 0.0f) atomicMax(dst + 0, __float_as_int(best.x));
-        if (best.y > 0.0f) atomicMax(dst + 1, __float_as_int(best.y));
-        if (best.z > 0.0f) atomicMax(dst + 2, __float_as_int(best.z));
-        if (best.w > 0.0f) atomicMax(dst + 3, __float_as_int(best.w));
-      }
-    };
+    if (!pb && !any_cell) continue;       // scatter-only launch, no point of the run has a target cell
     constexpr int kU = 4;
 #pragma unroll 1
     for (int i0 = 0; i0 < kL; i0 += kU) {
       float4 g[kU][4];
       float w[kU][4];
-      int o[kU][4], c[kU];
+      int o[kU][4];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int src = grp * kL + i0 + u;
@@ -490,7 +485,6 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
           o[u][k] = __shfl(off[k], src);
           w[u][k] = __shfl(wt[k], src);
         }
-        c[u] = __shfl(cell, src);
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u)
@@ -508,23 +502,38 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
           v.z = has ? v.z + g[u][k].z * w[u][k] : v.z;
           v.w = has ? v.w + g[u][k].w * w[u][k] : v.w;
         }
-        if (n0 + j < a.N) {
-          if (pb) *reinterpret_cast<float4*>(pb + (int64_t)j * a.po_n) = v;
-          if (ob) {
-            if (c[u] != cur) {
-              flush();
-              cur = c[u];
-              best = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            best.x = fmaxf(best.x, v.x);
-            best.y = fmaxf(best.y, v.y);
-            best.z = fmaxf(best.z, v.z);
-            best.w = fmaxf(best.w, v.w);
-          }
-        }
+        if (pb && n0 + j < a.N) *reinterpret_cast<float4*>(pb + (int64_t)j * a.po_n) = v;
+        if (kScatter) *reinterpret_cast<float4*>(tile + j * kC + 4 * l) = v;
       }
     }
-    if (ob) flush();
+    if (kScatter) {
+      // ---- phase C: lane = channel; kC = 32: the two halves of the wave sweep the two halves of the run
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int kHalves = kWave / kC;                 // 1 or 2
+      const int ch = lane % kC, half = lane / kC;
+      float* ob = a.out + (int64_t)b * a.Ho * a.Wo * a.op + ch;
+      const int n_valid = min(64, a.N - n0);
+      int cur = -1;
+      float best = 0.0f;
+#pragma unroll 4
+      for (int i = 0; i < 64 / kHalves; ++i) {
+        const int j = half * (64 / kHalves) + i;
+        const int c = kHalves == 1 ? __builtin_amdgcn_readlane(cell, i) : __shfl(cell, j);
+        const float v = tile[j * kC + ch];
+        if (j < n_valid) {
+          if (c != cur) {
+            if (cur >= 0 && best > 0.0f) atomicMax(reinterpret_cast<int*>(ob + (int64_t)cur * a.op), __float_as_int(best));
+            cur = c;
+            best = 0.0f;
+          }
+          best = fmaxf(best, v);
+        }
+      }
+      if (cur >= 0 && best > 0.0f) atomicMax(reinterpret_cast<int*>(ob + (int64_t)cur * a.op), __float_as_int(best));
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is rewritten by the next run
+    }
   }
 }
 
@@ -648,10 +657,20 @@ extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, con
     const int64_t runs = B * ((N + 63) / 64);
     const int64_t blocks = (runs + 3) / 4;
     dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));
-    if (C == 32)
-      hipLaunchKernelGGL((gather_scatter_cl4<32>), g, dim3(kBlock), 0, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL((gather_scatter_cl4<64>), g, dim3(kBlock), 0, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = out ? (size_t)4 * 64 * C * sizeof(float) : 0;       // one [64 points][C] tile per wave
+    KernelSetup ks;
+    if (C == 32 && out) {
+      if (int rc = kernel_setup(reinterpret_cast<const void*>(&gather_scatter_cl4<32, true>), lds, 0, &ks, "gather_scatter_cl")) return rc;
+      hipLaunchKernelGGL((gather_scatter_cl4<32, true>), g, dim3(kBlock), lds, s, a);
+    } else if (C == 32) {
+      hipLaunchKernelGGL((gather_scatter_cl4<32, false>), g, dim3(kBlock), 0, s, a);
+    } else if (out) {
+      if (int rc = kernel_setup(reinterpret_cast<const void*>(&gather_scatter_cl4<64, true>), lds, 0, &ks, "gather_scatter_cl")) return rc;
+      hipLaunchKernelGGL((gather_scatter_cl4<64, true>), g, dim3(kBlock), lds, s, a);
+    } else {
+      hipLaunchKernelGGL((gather_scatter_cl4<64, false>), g, dim3(kBlock), 0, s, a);
+    }
     return check_launch("gather_scatter_cl");
   }
   const int64_t runs = B * ((N + C - 1) / C);
