@@ -99,12 +99,17 @@ def algorithmic_bytes(label, ctx=None):
         b, h, w = (int(v) for v in dims.split("x"))
         return int(8 * b * h * w + ctx.get("stem_rows", 0) * 768)
     if name in ("stem_gemm", "stem_epilogue"):
-        # sparse DownSample2D 192 -> 32, stride 2 on the occupied cells: rows in (gemm), half-resolution map out (epilogue)
+        # sparse DownSample2D 192 -> 32, stride 2 on the occupied cells.  gemm: the compact rows in, the tap products Y out (a
+        # cell of parity class c yields (taps_c + 1) x 32 floats: its conv taps + the 1x1 pool branch); epilogue: Y in, the
+        # half-resolution map out.  (Until round 4 Y was charged to neither launch, which made the epilogue look like it
+        # moved 4.1 x its bytes.)
         b, h, w, cin = (int(v) for v in dims.split("x"))
         rows = ctx.get("stem_rows", b * h * w)
+        cls = ctx.get("stem_class_rows")
+        y_bytes = 4 * 32 * (sum(r * (taps + 1) for r, taps in zip(cls, (1, 2, 2, 4))) if cls is not None else rows * 3.25)
         if name == "stem_gemm":
-            return int(4 * rows * cin)
-        return 4 * b * (h // 2) * (w // 2) * 32
+            return int(4 * rows * cin + y_bytes)
+        return int(4 * b * (h // 2) * (w // 2) * 32 + y_bytes)
     return 0
 
 

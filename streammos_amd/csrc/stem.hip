@@ -238,20 +238,23 @@ struct StemEpiArgs {
   int B, H, W, Ho, Wo;
 };
 
-// lane = channel (C = 32): a wave handles two output pixels per iteration.
+// lane = 4 channels (C = 32: eight lanes per output pixel, eight pixels per wave instruction; round 4 -- it was one lane per
+// channel, two pixels per instruction: 4 x the instructions for the same bytes).
 // out[b, ho, wo, c] = relu( sum_{ky,kx} Y[cell(2ho-1+ky, 2wo-1+kx)][slot(ky,kx)][c]
 //                           + max_{valid window cells}( occupied ? Y[cell][q slot][c] : 0 ) + bias[c] )
+// The sums run in the same fixed tap order per channel as before: the same bits.
 template <int kC>
 __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
-  const int c = threadIdx.x % kC;
+  constexpr int kL = kC / 4;
+  const int c = 4 * (threadIdx.x % kL);
   const int n_out = a.B * a.Ho * a.Wo;            // < 2^31 (host check): 32-bit index arithmetic throughout
-  const float bias = a.bias[c];
+  const float4 bias = *reinterpret_cast<const float4*>(a.bias + c);
   const int start[4] = {a.meta[4], a.meta[5], a.meta[6], a.meta[7]};
   // the nine row ids come through a raw buffer descriptor: a tap outside the grid uses an offset past the end (reads 0)
   // instead of sitting under a lane-dependent branch -- nine conditional loads were nine exec-masked branches, each followed
   // by a full wait
   const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.row_of), 0, a.B * a.H * a.W * 4, 0x00020000);
-  for (int o = (int)blockIdx.x * (kBlock / kC) + (int)threadIdx.x / kC; o < n_out; o += (int)gridDim.x * (kBlock / kC)) {
+  for (int o = (int)blockIdx.x * (kBlock / kL) + (int)threadIdx.x / kL; o < n_out; o += (int)gridDim.x * (kBlock / kL)) {
     const int wo = o % a.Wo;
     const int t = o / a.Wo;
     const int ho = t % a.Ho, b = t / a.Ho;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
       const int r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, inb ? (unsigned)((b * a.H + y) * a.W + x) * 4u : 0x80000000u, 0, 0);
       rid[t9] = inb ? r : -2;     // -1: empty cell, -2: outside the grid
     }
-    float va[9], vq[9];
+    float4 va[9], vq[9];
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
       const int ky = t9 / 3, kx = t9 % 3;
@@ -274,17 +277,29 @@ __global__ __launch_bounds__(kBlock) void stem_epilogue(StemEpiArgs a) {
       const int cls = ey * 2 + ex, taps = (1 + ey) * (1 + ex);
       const int slot = (ey ? ky >> 1 : 0) * (1 + ex) + (ex ? kx >> 1 : 0);
       const float* row = a.y[cls] + (int64_t)max(rid[t9] - start[cls], 0) * ((taps + 1) * kC);
-      va[t9] = row[slot * kC + c];
-      vq[t9] = row[taps * kC + c];
+      va[t9] = *reinterpret_cast<const float4*>(row + slot * kC + c);
+      vq[t9] = *reinterpret_cast<const float4*>(row + taps * kC + c);
     }
-    float acc = 0.0f, qmax = -INFINITY;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), qmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
-      acc = rid[t9] >= 0 ? acc + va[t9] : acc;
+      const bool occ = rid[t9] >= 0, empty = rid[t9] == -1;
+      acc.x = occ ? acc.x + va[t9].x : acc.x;
+      acc.y = occ ? acc.y + va[t9].y : acc.y;
+      acc.z = occ ? acc.z + va[t9].z : acc.z;
+      acc.w = occ ? acc.w + va[t9].w : acc.w;
       // an empty cell inside the grid contributes 0 to the pooled branch; outside the grid nothing (padding of the pool)
-      qmax = rid[t9] >= 0 ? fmaxf(qmax, vq[t9]) : (rid[t9] == -1 ? fmaxf(qmax, 0.0f) : qmax);
+      qmax.x = occ ? fmaxf(qmax.x, vq[t9].x) : (empty ? fmaxf(qmax.x, 0.0f) : qmax.x);
+      qmax.y = occ ? fmaxf(qmax.y, vq[t9].y) : (empty ? fmaxf(qmax.y, 0.0f) : qmax.y);
+      qmax.z = occ ? fmaxf(qmax.z, vq[t9].z) : (empty ? fmaxf(qmax.z, 0.0f) : qmax.z);
+      qmax.w = occ ? fmaxf(qmax.w, vq[t9].w) : (empty ? fmaxf(qmax.w, 0.0f) : qmax.w);
     }
-    a.out[(int64_t)o * a.op + c] = fmaxf((acc + qmax) + bias, 0.0f);
+    float4 r;
+    r.x = fmaxf((acc.x + qmax.x) + bias.x, 0.0f);
+    r.y = fmaxf((acc.y + qmax.y) + bias.y, 0.0f);
+    r.z = fmaxf((acc.z + qmax.z) + bias.z, 0.0f);
+    r.w = fmaxf((acc.w + qmax.w) + bias.w, 0.0f);
+    *reinterpret_cast<float4*>(a.out + (int64_t)o * a.op + c) = r;
   }
 }
 
@@ -355,8 +370,11 @@ extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const i
 
 extern "C" int smos_stem_epilogue(const float* const* y4, const int32_t* meta, const int32_t* row_of, const float* bias,
                                   float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t C, smos_stream_t stream) {
-  SMOS_REQUIRE(B > 0 && H > 1 && W > 1 && C == 32 && out_pitch >= C, "stem_epilogue: bad sizes (C must be 32)");
+  SMOS_REQUIRE(B > 0 && H > 1 && W > 1 && C == 32 && out_pitch >= C && out_pitch % 4 == 0, "stem_epilogue: bad sizes (C must be 32, pitch a multiple of 4)");
   SMOS_REQUIRE(y4 && meta && row_of && bias && out, "stem_epilogue: null pointer");
+  SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y4[0]) |
+                 reinterpret_cast<uintptr_t>(y4[1]) | reinterpret_cast<uintptr_t>(y4[2]) | reinterpret_cast<uintptr_t>(y4[3])) & 15) == 0,
+               "stem_epilogue: pointers must be 16-byte aligned");
   SMOS_REQUIRE(B * H * W < (1LL << 29), "stem_epilogue: grid too large for 32-bit buffer offsets");
   StemEpiArgs a;
   for (int k = 0; k < 4; ++k) a.y[k] = y4[k];
@@ -365,6 +383,6 @@ extern "C" int smos_stem_epilogue(const float* const* y4, const int32_t* meta, c
   a.Ho = (int)((H + 2 - 3) / 2 + 1);
   a.Wo = (int)((W + 2 - 3) / 2 + 1);
   const int64_t n_out = B * a.Ho * a.Wo;
-  hipLaunchKernelGGL((stem_epilogue<32>), dim3(grid_for(n_out * 32, kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((stem_epilogue<32>), dim3(grid_for(n_out * 8, kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream, a);
   return check_launch("stem_epilogue");
 }

@@ -483,8 +483,16 @@ class StreamRunner:
             if self.pipeline:
                 res = self._pipelined(dev, next_dev)
             else:
-                batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
-                res = self.model.infer(batch, self.frame, self.memory)
+                eng = self.model._engine_for(dev["pcds_xyzi"])
+                if eng is not None:
+                    # the same kernels as the pipelined form, one stream: encode, then decode without the three aux heads the
+                    # runner never reads (model.infer computes them: 3 GEMMs + 2 resizes per frame that the two-stream step does
+                    # not run, so serial traces would not be traces of the timed step)
+                    enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
+                    res = eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False)
+                else:
+                    batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
+                    res = self.model.infer(batch, self.frame, self.memory)
             pred_cls, self.memory = res[0], res[-1]          # 5-tuple (stage 1) or 6-tuple (StreamMOS_seg)
             labels = ops.tta_argmax(pred_cls)
             if len(res) == 6:
