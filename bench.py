@@ -88,6 +88,15 @@ def algorithmic_bytes(label, ctx=None):
         b, ho, wo, c = (int(v) for v in dst.split("x"))
         cells = sum(int(hw.split("x")[0]) * int(hw.split("x")[1]) for hw in srcs.split("+"))
         return 4 * (2 * b * ho * wo * c + b * cells * 9 * c)
+    if name == "tfusion_layer":
+        # sampled + query in, the layer's output (and the next layer's projection) out, the weight stream once (csrc/tfusion.hip)
+        tokens, c, ffn, nq = _tfusion_layer_dims(dims)
+        return 4 * (3 * tokens * c + tokens * nq + c * c + 2 * c * ffn + c * nq)
+    if name == "tfusion_project":
+        src, couts = dims.split("->")
+        tokens, c = (int(v) for v in src.split("x"))
+        couts = [int(v) for v in couts.split("+")]
+        return 4 * (len(couts) * tokens * c + tokens * sum(couts) + c * sum(couts))
     if name == "conv_cl":
         # own implicit-GEMM conv (csrc/conv_igemm.hip): label B x Cin x H x W -> Cout x Ho x Wo k KHxKW [+res]
         geo = _conv_geometry(dims)
@@ -111,6 +120,13 @@ def algorithmic_bytes(label, ctx=None):
             return int(4 * rows * cin + y_bytes)
         return int(4 * b * (h // 2) * (w // 2) * 32 + y_bytes)
     return 0
+
+
+def _tfusion_layer_dims(dims):
+    """tfusion_layer[tokens x 128 x ffn (+qN)] -> (tokens, d_model, ffn, channels of the next projection)"""
+    core, _, q = dims.partition("+q")
+    tokens, c, ffn = (int(v) for v in core.split("x"))
+    return tokens, c, ffn, int(q) if q else 0
 
 
 def _conv_geometry(dims):
@@ -138,6 +154,13 @@ def algorithmic_flops(label, ctx=None):
     if name == "conv_cl":
         geo = _conv_geometry(dims)
         return 2 * geo["b"] * geo["ho"] * geo["wo"] * geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"]
+    if name == "tfusion_layer":
+        tokens, c, ffn, nq = _tfusion_layer_dims(dims)
+        return 2 * tokens * (c * c + 2 * c * ffn + c * nq)
+    if name == "tfusion_project":
+        src, couts = dims.split("->")
+        tokens, c = (int(v) for v in src.split("x"))
+        return 2 * tokens * c * sum(int(v) for v in couts.split("+"))
     if name == "stem_gemm":
         # sparse DownSample2D 192 -> 32 on the occupied cells: a cell of parity class c feeds STEM_TAPS[c] conv taps plus the
         # 1x1 pool branch (csrc/stem.hip).  Needs the frames' occupancy; without it the launch is priced by its bytes only.

@@ -31,6 +31,8 @@ python3 $R/profiles/step_breakdown.py $T > $OUT/step_breakdown.txt 2>&1 || true
 S2=$(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1); T2=$(find $OUT/trace_serial -name "*kernel_trace.csv" | head -1)
 cp $S2 $OUT/kernel_stats_serial.csv
 python3 $R/profiles/step_breakdown.py $T2 > $OUT/step_breakdown_serial.txt 2>&1 || true
+python3 $R/profiles/step_timeline.py $T2 > $OUT/step_timeline_serial.csv 2>&1 || true
+python3 $R/profiles/step_timeline.py $T > $OUT/step_timeline.csv 2>&1 || true
 # per-LABEL durations of the serial trace (launch order = dispatch order), with the roofline fraction of every labelled launch
 grep "^{" $OUT/bench_trace_serial.log | tail -1 > $OUT/bench_traced_serial.json.log || true
 python3 $R/profiles/label_durations.py $T2 $OUT/labels_serial.json $OUT/bench_traced_serial.json.log > $OUT/label_durations.csv 2> $OUT/label_durations.err || true
