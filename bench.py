@@ -617,7 +617,7 @@ def family_roofline(model, device, dev_frames, args, ctx, one_step):
     `frac`: an MFMA-bound family is priced on the FLOPs it EXECUTES on the matrix cores (a Winograd launch issues 4/9 of the
     direct count); `algorithmic_frac` beside it counts the direct-form FLOPs and may exceed 1."""
     from streammos_amd import profiling, streaming
-    serial = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=False)
+    serial = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=False, skip_padding=not args.no_skip_padding)
     n_ser = 8
     for i in range(2):
         serial.step(*dev_frames[i % len(dev_frames)])
@@ -747,6 +747,9 @@ def main():
     ap.add_argument("--train-steps", type=int, default=None,
                     help="timed stage-2 DDP training steps on all ranks (BASELINE configs[4]; 0 = skip; default 3, 0 with "
                          "--dry-launch); reported beside value")
+    ap.add_argument("--no-skip-padding", action="store_true",
+                    help="compute the point head on the padding tail of every scan too (A/B; the runner's default leaves those "
+                         "logits at zero: val_StreamMOS.py:113 cuts them off)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only rehearse the rank launch: gloo ranks join the group, time a barrier, rank 0 prints n_gpus")
     ap.add_argument("--label-log", default=None,
@@ -793,7 +796,7 @@ def main():
     model.load_state_dict(state, strict=True)
     model.engine_layout = args.layout
     runner = streaming.StreamRunner(model, device, vote=not args.no_vote, graph=args.graph, split=args.split,
-                                    pipeline=not (args.no_pipeline or args.graph))
+                                    pipeline=not (args.no_pipeline or args.graph), skip_padding=not args.no_skip_padding)
 
     frames = make_frames(args.frames, seq_seed=rank)
     dev_frames = [(runner.upload(s, raw), pose) for s, raw, pose in frames]
@@ -873,7 +876,9 @@ def main():
             "config": {"workload": "configs[1]: full StreamMOS streaming inference, 1 sequence per GPU, B=4 TTA x T=3 "
                                    "x N=160000 padded points (120k-point synthetic HDL-64E scans), 8-frame voxel "
                                    "voting %s" % ("off" if args.no_vote else "on"),
-                       "tta": 4, "frame_point_num": FRAME_POINT_NUM, "parallelism": "sequence-shard x%d" % world},
+                       "tta": 4, "frame_point_num": FRAME_POINT_NUM, "parallelism": "sequence-shard x%d" % world,
+                       "real_points_per_scan": round(float(np.mean([d["n_valid"] for d, _ in dev_frames]))),
+                       "padding_tail": "point head skipped (logits zero)" if not args.no_skip_padding else "computed"},
             "roofline": roof,
             "path_roofline": {"bound": "hbm", "achieved": round(value / world * ALG_GB_PER_SCAN, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(value / world * ALG_GB_PER_SCAN / HBM_PEAK_GBS, 4),
@@ -897,7 +902,8 @@ def main():
         }
         if world == 1 and not args.no_raw:
             # PCIe-inclusive variant (never `value`): raw scans uploaded every step, preprocessing on the device
-            raw_runner = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=not args.no_pipeline)
+            raw_runner = streaming.StreamRunner(model, device, vote=not args.no_vote, pipeline=not args.no_pipeline,
+                                                skip_padding=not args.no_skip_padding)
             from streammos_amd import synth as _synth
             raw = [(_synth.synthetic_scan(k), _synth.synthetic_pose(k)) for k in range(6)]
             def raw_window(i):

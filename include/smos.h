@@ -356,6 +356,12 @@ int smos_upconv_ypass(const float* conv_a, int64_t a_pitch, const float* bias, c
 int64_t smos_point_head_weight_floats(void);
 int smos_point_head(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N, int64_t K1,
                     int64_t M1, int64_t M2, int64_t M3, smos_stream_t stream);
+/* The same with the scan's padding tail left out: n_live (DEVICE int32, may be NULL = no tail) says how many points at the
+ * front of every sample are real -- the reference pads every scan to frame_point_num with points at -1000
+ * (datasets/data_StreamMOS.py:568-571) and cuts their predictions off again (val_StreamMOS.py:113); the logits of points
+ * [*n_live, N) are written as zeros without being computed.  The streaming runner's form; AttNet.infer computes all N. */
+int smos_point_head_live(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N, int64_t K1,
+                         int64_t M1, int64_t M2, int64_t M3, const int32_t* n_live, smos_stream_t stream);
 
 /* smos_pointnet_scatter with a COMPACT target: rows [n_rows, T*cout] (zero-filled by smos_stem_scan) instead of
  * the dense [B,H,W,T*cout] grid; the features of cell (b, y, x) go to row row_of[b][y][x] (smos_stem_scan). */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "smos_pointnet_scatter_rows": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "smos_point_head_weight_floats": [],
     "smos_point_head": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp],
+    "smos_point_head_live": [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp],
     "smos_conv_cl_sum_chunks": [i64, i64],
     "smos_conv_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "smos_conv_rows_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp],

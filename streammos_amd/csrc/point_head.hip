@@ -24,6 +24,7 @@ struct HeadArgs {
   const float* rows;     // [P, *] row pitch rp
   const float* wprep;    // kHeadLds floats: A1 | A2 | A3 | b1 | b2 | b3 (padded to 32)
   float* out;            // [B, M3, N]
+  const int32_t* n_live; // device: points [*n_live, N) of every sample are the padding tail of the scan (null: none)
   int64_t rp;
   int B, N, M3;
 };
@@ -43,10 +44,18 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
   constexpr int kWaves = kHeadBlock / 64;
   const int tiles_per_sample = (a.N + 31) / 32;
   const int n_tiles = a.B * tiles_per_sample;
+  const int n_live = a.n_live ? min(max(*a.n_live, 0), a.N) : a.N;
   for (int tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
     const int b = tile / tiles_per_sample;
     const int n = (tile - b * tiles_per_sample) * 32 + col;
     const bool valid = n < a.N;
+    if (n - col >= n_live) {
+      // a tile in the padding tail (datasets/data_StreamMOS.py:568-571 pads every scan to frame_point_num with points at
+      // -1000 that val_StreamMOS.py:113 cuts off again): its logits are never read; they are written as zeros
+      if (valid)
+        for (int ch = 0; ch < a.M3; ++ch) a.out[((int64_t)b * a.M3 + ch) * a.N + n] = 0.0f;
+      continue;
+    }
     const float4* src = reinterpret_cast<const float4*>(a.rows + ((int64_t)b * a.N + (valid ? n : 0)) * a.rp + hh * kS1);
 
     // ---- layer 1: 192 -> 96, K streamed in four quarters
@@ -129,8 +138,18 @@ using namespace smos;
 
 extern "C" int64_t smos_point_head_weight_floats(void) { return kHeadLds; }
 
+extern "C" int smos_point_head_live(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N,
+                                    int64_t K1, int64_t M1, int64_t M2, int64_t M3, const int32_t* n_live, smos_stream_t stream);
+
 extern "C" int smos_point_head(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N,
                                int64_t K1, int64_t M1, int64_t M2, int64_t M3, smos_stream_t stream) {
+  return smos_point_head_live(rows, row_pitch, wprep, out, B, N, K1, M1, M2, M3, nullptr, stream);
+}
+
+// n_live (device int32, may be null): the first *n_live points of every sample are real, the rest is the scan's padding tail,
+// whose logits are written as zeros without being computed.
+extern "C" int smos_point_head_live(const float* rows, int64_t row_pitch, const float* wprep, float* out, int64_t B, int64_t N,
+                                    int64_t K1, int64_t M1, int64_t M2, int64_t M3, const int32_t* n_live, smos_stream_t stream) {
   SMOS_REQUIRE(K1 == kK1 && M1 == kM1 && M2 == kM2 && M3 >= 1 && M3 <= 32, "point_head: built for 192 -> 96 -> 64 -> (<=32)");
   SMOS_REQUIRE(B > 0 && N > 0 && row_pitch >= K1 && row_pitch % 4 == 0 && B * ((N + 31) / 32) < (1LL << 31), "point_head: bad sizes");
   SMOS_REQUIRE(rows && wprep && out && (reinterpret_cast<uintptr_t>(rows) & 15) == 0, "point_head: null / unaligned pointer");
@@ -138,7 +157,7 @@ extern "C" int smos_point_head(const float* rows, int64_t row_pitch, const float
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&point_head), kHeadLds * sizeof(float), 0, &ks, "point_head")) return rc;
   const int cus = ks.cus;
   HeadArgs a;
-  a.rows = rows; a.wprep = wprep; a.out = out; a.rp = row_pitch; a.B = (int)B; a.N = (int)N; a.M3 = (int)M3;
+  a.rows = rows; a.wprep = wprep; a.out = out; a.n_live = n_live; a.rp = row_pitch; a.B = (int)B; a.N = (int)N; a.M3 = (int)M3;
   const int64_t tiles = B * ((N + 31) / 32);
   const int64_t want = (tiles + 7) / 8;
   hipLaunchKernelGGL(point_head, dim3((unsigned)(want < cus ? want : cus)), dim3(kHeadBlock), kHeadLds * sizeof(float),

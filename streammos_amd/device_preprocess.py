@@ -68,7 +68,7 @@ class DevicePreprocessor:
                 if t == 0:
                     first = (mask, prefix, n)
         built = {"pcds_xyzi": xyzi, "pcds_coord": coord, "pcds_sphere_coord": sphere, "mask": first[0], "prefix": first[1],
-                 "n_raw": first[2], "in_range_counts": counts}
+                 "n_raw": first[2], "in_range_counts": counts, "n_live": counts[0:1]}
         if strict:
             self.check_capacity(built)
         return built

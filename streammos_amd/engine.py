@@ -242,15 +242,16 @@ class InferenceEngine:
         except (RuntimeError, AttributeError):
             return torch.relu_(torch.addmm(wb[1], x, w.t()))
 
-    def _point_heads(self, fuse, aux, k, x2):
-        """CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3 (and the stage-2 refine head)."""
+    def _point_heads(self, fuse, aux, k, x2, n_live=None):
+        """CatFusion + PredBranch as point-major GEMMs: [B*N, 192] -> 96 -> 64 -> 3 (and the stage-2 refine head).
+        n_live (device int32, runner only): real points at the front of every sample; the padding tail's logits are zeros."""
         bs, n = fuse.shape[0], fuse.shape[1]
         rows = fuse.view(bs * n, -1)
         a3 = tuple(aux) if isinstance(aux, (tuple, list)) else (aux[:, :k], aux[:, k:2 * k], aux[:, 2 * k:])
 
         def head(l1, l2, pr, fused):
             if self.fused_head and fused is not None and fuse.stride(1) % 4 == 0:
-                return ops.point_head(fuse, fused[0], fused[1]).unsqueeze(-1)
+                return ops.point_head(fuse, fused[0], fused[1], n_live=n_live).unsqueeze(-1)
             z = self._linear_relu(self._linear_relu(rows, l1), l2)
             out = torch.addmm(pr[1], z, pr[0].view(pr[0].shape[0], -1).t())
             return out.view(bs, n, -1).permute(0, 2, 1).contiguous().unsqueeze(-1)
@@ -372,11 +373,13 @@ class InferenceEngine:
                 return self._encode_cl(point_feat, pcds_coord, pcds_sphere_coord)
             return self._encode(point_feat, pcds_coord, pcds_sphere_coord)
 
-    def decode(self, enc, memory=None, want_aux=True):
+    def decode(self, enc, memory=None, want_aux=True, n_live=None):
         """want_aux=False: the three BEV aux maps (training-time supervision heads, models/StreamMOS.py:106-111) are not
         computed and come back as None -- the streaming runner throws them away (val_StreamMOS.py:97 uses pred_cls only);
-        AttNet.infer always returns them."""
-        return self.decode_heads(enc, self.decode_memory(enc, memory), want_aux)
+        AttNet.infer always returns them.  n_live (device int32 tensor, runner only): the number of real points at the front
+        of every sample of the current scan; the point head leaves the padding tail's logits at zero (val_StreamMOS.py:113
+        cuts that tail off; datasets/data_StreamMOS.py:568-571 creates it).  AttNet.infer computes all N."""
+        return self.decode_heads(enc, self.decode_memory(enc, memory), want_aux, n_live)
 
     def decode_memory(self, enc, memory=None):
         """The only part that is serial across frames: third BEV stage + deformable-attention fusion with the previous
@@ -387,11 +390,11 @@ class InferenceEngine:
                 return self._temporal_fusion(x2, memory, channels_last=True)
             return self._temporal_fusion(enc["x2"], memory)
 
-    def decode_heads(self, enc, x2, want_aux=True):
+    def decode_heads(self, enc, x2, want_aux=True, n_live=None):
         """Decoder convs, aux heads, bev->point gather and the point heads; nothing here feeds the next frame."""
         with torch.no_grad(), self._conv_flags():
             if self.layout == "cl":
-                return self._decode_cl(enc, x2, want_aux)
+                return self._decode_cl(enc, x2, want_aux, n_live)
             return self._decode(enc, x2)
 
     # ---- channels-last path -----------------------------------------------------------------------
@@ -529,7 +532,7 @@ class InferenceEngine:
         # res2 on the encode side 158.6 vs 167.5 scans/s)
         return {"x0cat": x0cat, "x1cat": x1cat, "fuse": fuse, "bev_xy": bev_xy, "o1": o1, "o2": o2}
 
-    def _decode_cl(self, enc, x2, want_aux=True):
+    def _decode_cl(self, enc, x2, want_aux=True, n_live=None):
         x0cat, x1cat, fuse, bev_xy, o1, o2 = enc["x0cat"], enc["x1cat"], enc["fuse"], enc["bev_xy"], enc["o1"], enc["o2"]
         k = self.aux[2]
         if self.upconv:
@@ -555,7 +558,7 @@ class InferenceEngine:
             aux = F.conv2d(dec_in, self.aux[0], self.aux[1]) if want_aux else (None, None, None)
         bev_feat = self._conv(y, self.conv_2[0], self.conv_2[1], LEAKY)
         ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
-        return self._point_heads(fuse, aux, k, x2)
+        return self._point_heads(fuse, aux, k, x2, n_live)
 
     def _encode(self, point_feat, pcds_coord, pcds_sphere_coord):
         """Everything that does NOT depend on the previous frame: point MLP + input scatter, the three BEV stages

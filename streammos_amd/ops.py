@@ -481,19 +481,24 @@ def point_head_prepare(l1, l2, l3):
     return flat, int(w3.shape[0])
 
 
-def point_head(rows, wprep, m3, out=None):
-    """rows [B, N, >=192] float32 (row stride a multiple of 4 floats) -> logits [B, m3, N]."""
-    _require_cuda("point_head", rows, wprep, out)
+def point_head(rows, wprep, m3, out=None, n_live=None):
+    """rows [B, N, >=192] float32 (row stride a multiple of 4 floats) -> logits [B, m3, N].
+    n_live: optional device int32 tensor (its first element is read): the number of REAL points at the front of every sample;
+    the logits of the scan's padding tail [n_live, N) come back as zeros without being computed (the streaming runner's form:
+    val_StreamMOS.py:113 cuts them off)."""
+    _require_cuda("point_head", rows, wprep, out, n_live)
     if rows.dtype != torch.float32 or rows.dim() != 3 or rows.stride(2) != 1 or rows.stride(0) != rows.shape[1] * rows.stride(1):
         raise RuntimeError("point_head: rows must be a float32 [B, N, C] tensor with dense point rows")
+    if n_live is not None and (n_live.dtype != torch.int32 or n_live.numel() < 1):
+        raise RuntimeError("point_head: n_live must be a device int32 tensor")
     b, n = rows.shape[0], rows.shape[1]
     if out is None:
         out = torch.empty((b, m3, n), dtype=torch.float32, device=rows.device)
     lib = _lib.load()
     with _on(rows.device), profiling.span("point_head[%dx%d]" % (b, n)):
-        rc = lib.smos_point_head(rows.data_ptr(), rows.stride(1), wprep.data_ptr(), out.data_ptr(), b, n, 192, 96, 64, m3,
-                                 _stream(rows))
-    _lib.check(rc, "smos_point_head")
+        rc = lib.smos_point_head_live(rows.data_ptr(), rows.stride(1), wprep.data_ptr(), out.data_ptr(), b, n, 192, 96, 64, m3,
+                                      n_live.data_ptr() if n_live is not None else None, _stream(rows))
+    _lib.check(rc, "smos_point_head_live")
     return out
 
 

@@ -214,7 +214,8 @@ def concurrent_stream(device, candidates=8, spin_cycles=400000):
 class StreamRunner:
     """infer -> TTA reduce -> labels for the raw scan -> voxel voting, all on one device, one stream."""
 
-    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False, split=1, pipeline=False):
+    def __init__(self, model, device="cuda:0", vote=True, recip_quantize=False, graph=False, split=1, pipeline=False,
+                 skip_padding=True):
         """graph=True captures the network forward of a frame into hipGraphs (first frame: learned memory embedding;
         later frames: recurrent memory) that are replayed on static buffers -- one launch per scan instead of ~180.
         split=k additionally cuts the TTA batch into k independent groups (TTA variants never interact inside the
@@ -235,6 +236,12 @@ class StreamRunner:
         # scatters, the BEV / range-view stages: ~60 % of the work) is issued on a second HIP stream while frame t
         # is decoded on the main one.  step() must then be given the next frame's inputs (one frame of look-ahead).
         self.pipeline = pipeline
+        # skip_padding: the reference pads every scan to frame_point_num with points at -1000 (datasets/data_StreamMOS.py:568-571)
+        # and cuts their predictions off again (val_StreamMOS.py:113).  The runner tells the point head how many points are
+        # real (a device-side count: no host sync); the padding tail's logits come back as zeros instead of being computed
+        # (25 % of the points of a SemanticKITTI scan at frame_point_num = 160 000, 40 % of the bench's synthetic ones).
+        # Labels, raw labels and votes of every real point are unchanged; AttNet.infer (the reference API) computes all N.
+        self.skip_padding = bool(skip_padding)
         self._side = concurrent_stream(self.device) if pipeline else None
         self._pre_enc = None
         self.reset()
@@ -337,6 +344,7 @@ class StreamRunner:
         dev["valid_index"] = torch.from_numpy(np.nonzero(sample["valid_mask"])[0]).to(self.device)
         dev["n_raw"] = int(sample["valid_mask"].shape[0])
         dev["n_valid"] = int(sample["valid_mask"].sum())
+        dev["n_live"] = torch.tensor([dev["n_valid"]], dtype=torch.int32).to(self.device)     # real points at the front of every sample
         if raw_scan is not None:
             dev["raw_scan"] = torch.from_numpy(np.ascontiguousarray(raw_scan)).to(self.device)
         dev["ready"] = torch.cuda.Event()            # consumers on other HIP streams wait for the copies above
@@ -466,7 +474,8 @@ class StreamRunner:
                     t.record_stream(main)
                     t.record_stream(self._side)
             self._pre_enc = (next_dev, nxt)
-        return eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False)    # the runner uses pred_cls only
+        return eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False,       # the runner uses pred_cls only
+                          n_live=dev.get("n_live") if self.skip_padding else None)
 
     @torch.no_grad()
     def step(self, dev, pose=None, next_dev=None):
@@ -489,7 +498,8 @@ class StreamRunner:
                     # runner never reads (model.infer computes them: 3 GEMMs + 2 resizes per frame that the two-stream step does
                     # not run, so serial traces would not be traces of the timed step)
                     enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
-                    res = eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False)
+                    res = eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False,
+                                     n_live=dev.get("n_live") if self.skip_padding else None)
                 else:
                     batch = {k: dev[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
                     res = self.model.infer(batch, self.frame, self.memory)

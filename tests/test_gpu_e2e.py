@@ -68,8 +68,12 @@ def test_stream_runner_with_voting_matches_oracle(model):
         want, _, _, _, memory = oracle.stage_forward(*(torch.from_numpy(sample[k]) for k in
                                                        ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")), memory)
         want_lab, _ = net_torch.tta_labels(want)
-        agree = (out["labels"].cpu().long() == want_lab).float().mean().item()
-        err = (out["pred_cls"].cpu() - want).abs().max().item() / want.abs().max().item()
+        # the runner leaves the scan's padding tail to the point head as zeros (StreamRunner(skip_padding=True): the reference
+        # cuts that tail off, val_StreamMOS.py:113); everything in front of it is compared
+        nv = int(sample["valid_mask"].sum())
+        assert nv < 2048 and float(out["pred_cls"][:, :, nv:].abs().max()) == 0.0
+        agree = (out["labels"].cpu().long()[:nv] == want_lab[:nv]).float().mean().item()
+        err = (out["pred_cls"].cpu()[:, :, :nv] - want[:, :, :nv]).abs().max().item() / want.abs().max().item()
         print("runner frame %d vs oracle: logits %.2e of range, TTA labels %.6f" % (i, err, agree))
         # ~10x the observed error (fp32 on both sides, summation order only); 2048 points: one flipped label = 4.9e-4
         assert err <= 2e-5 and agree >= 0.9995, (i, err, agree)
@@ -340,7 +344,9 @@ def test_graph_replay_equals_eager(model):
     import copy
     for graph in (False, True, 2):
         # graph capture reconfigures the engine of the model it is given: use a private copy
-        runner = streaming.StreamRunner(copy.deepcopy(model), DEV, vote=False, graph=bool(graph), split=2 if graph == 2 else 1)
+        # (skip_padding=False: the graphs capture AttNet.infer, which computes the padding tail's logits too)
+        runner = streaming.StreamRunner(copy.deepcopy(model), DEV, vote=False, graph=bool(graph), split=2 if graph == 2 else 1,
+                                        skip_padding=False)
         outs = []
         for i in range(4):
             idx = preprocess.window_indices(i, 6, 3)
@@ -369,7 +375,7 @@ def test_concurrent_streams_equal_separate_streams(model):
         seqs.append((scans, poses))
     solo = []
     for scans, poses in seqs:
-        r = streaming.StreamRunner(model, DEV, vote=False)
+        r = streaming.StreamRunner(model, DEV, vote=False, skip_padding=False)     # MultiStreamRunner computes every logit
         outs = []
         for i in range(3):
             idx = preprocess.window_indices(i, 6, 3)
@@ -464,7 +470,7 @@ def test_eight_concurrent_streams_full_size(model):
     up = streaming.StreamRunner(model, DEV, vote=False)
     solo = []
     for q in range(S):
-        r = streaming.StreamRunner(model, DEV, vote=True)
+        r = streaming.StreamRunner(model, DEV, vote=True, skip_padding=False)      # MultiStreamRunner computes every logit
         r.voter.window = n_frames
         outs = []
         for f in range(n_frames):
@@ -538,3 +544,45 @@ def test_pipelined_runner_on_a_warm_engine_at_full_size(model):
         # same kernels on the same inputs; a library conv that splits K with atomic adds may differ in the last bits
         assert torch.equal(p0, p1) or (p0 - p1).abs().max().item() <= 1e-6 * p0.abs().max().item(), k
         assert (r0 == r1).float().mean().item() >= 0.99999, k
+
+
+@pytest.mark.parametrize("pipe", [False, True])
+def test_runner_skipping_the_padding_tail_changes_no_real_point(model, pipe):
+    """StreamRunner(skip_padding=True) (the default) tells the point head how many points of the scan are real
+    (datasets/data_StreamMOS.py:568-571 pads to frame_point_num, val_StreamMOS.py:113 cuts the tail off): the logits of every
+    real point, the TTA labels, the raw-scan labels and the votes are BIT-identical to the runner that computes the tail too;
+    the tail's logits are zeros.  Host-preprocessed and device-preprocessed frames (the count lives on the device), plain and
+    two-stream."""
+    spec = preprocess.VoxelSpec()
+    n_frames = 4
+    scans = [synth.synthetic_scan(300 + k, 16, 120) for k in range(n_frames + 2)]
+    poses = [synth.synthetic_pose(k) for k in range(n_frames + 2)]
+    res = {}
+    for skip in (False, True):
+        runner = streaming.StreamRunner(model, DEV, vote=True, pipeline=pipe, skip_padding=skip)
+        runner.voter.window = 3
+        outs, devs, nvs = [], [], []
+        for i in range(n_frames):
+            idx = preprocess.window_indices(i, n_frames + 2, 3)
+            sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
+            devs.append(runner.upload(sample, scans[i]))
+            nvs.append(int(sample["valid_mask"].sum()))
+        for i in range(n_frames):
+            o = runner.step(devs[i], poses[i], next_dev=devs[i + 1] if pipe and i + 1 < n_frames else None)
+            outs.append((o["pred_cls"].clone(), o["labels"].clone(), o["raw_labels"].clone(), [(f, l.clone()) for f, l in o["voted"]]))
+        # the same through step_raw: the in-range count never leaves the device
+        raw_runner = streaming.StreamRunner(model, DEV, vote=False, pipeline=pipe, skip_padding=skip)
+        raws = []
+        for i in range(2):
+            idx = preprocess.window_indices(i, n_frames + 2, 3)
+            o = raw_runner.step_raw([scans[j] for j in idx], [poses[j] for j in idx], frame_point_num=2048)
+            raws.append((o["pred_cls"].clone(), o["raw_labels"].clone()))
+        res[skip] = (outs, nvs, raws)
+    (full, nvs, raw_full), (lean, _, raw_lean) = res[False], res[True]
+    for (p0, l0, r0, v0), (p1, l1, r1, v1), nv in zip(full, lean, nvs):
+        assert 0 < nv < 2048
+        assert torch.equal(p0[:, :, :nv], p1[:, :, :nv]) and float(p1[:, :, nv:].abs().max()) == 0.0 and float(p0[:, :, nv:].abs().max()) > 0
+        assert torch.equal(l0[:nv], l1[:nv]) and torch.equal(r0, r1)
+        assert [f for f, _ in v0] == [f for f, _ in v1] and all(torch.equal(a, b) for (_, a), (_, b) in zip(v0, v1))
+    for (p0, r0), (p1, r1), nv in zip(raw_full, raw_lean, nvs):
+        assert torch.equal(p0[:, :, :nv], p1[:, :, :nv]) and float(p1[:, :, nv:].abs().max()) == 0.0 and torch.equal(r0, r1)
