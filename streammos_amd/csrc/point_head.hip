@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = 8 * (r >> 2) + 4 * hh + (r & 3);
-        if (ch < a.M3) a.out[((int64_t)b * a.M3 + ch) * a.N + n] = c3[r] + B3[ch];
+        if (ch < a.M3) a.out[((int64_t)b * a.M3 + ch) * a.N + n] = n < n_live ? c3[r] + B3[ch] : 0.0f;   // tail inside a live tile
       }
     }
   }
