@@ -369,6 +369,13 @@ int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K,
                                const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
                                int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
                                int32_t cmid, int32_t cout, smos_stream_t stream);
+/* The same, told how many points of the current scan are real (n_live: DEVICE int32 or NULL; see smos_point_head_live): the point
+ * rows of the padding tail [*n_live, N) are not computed and not written.  The scatter itself is unaffected (padding points lie
+ * outside the grid). */
+int smos_pointnet_scatter_rows_live(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
+                                    int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                                    int32_t cmid, int32_t cout, const int32_t* n_live, smos_stream_t stream);
 /* BilinearSample (networks/backbone.py:453-475) of grid [B,C,Hg,Wg] (element strides grid_stride[4]) at
  * gcoord*gscale, fused with VoxelMaxPool of the result into out [B,Ho,Wo,C] (channels-last) at
  * int(scoord*sscale) (networks/multi_view_encoder.py:395-404,410-419).  out may be NULL (gather only);
@@ -442,6 +449,11 @@ int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, const float* g
                            const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch, float* pts_out,
                            int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
                            int64_t Wo, smos_stream_t stream);
+/* The same with n_live (DEVICE int32 or NULL; see smos_point_head_live): point rows of the padding tail are not written. */
+int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
+                                const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch, float* pts_out,
+                                int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
+                                int64_t Wo, const int32_t* n_live, smos_stream_t stream);
 
 #ifdef __cplusplus
 }

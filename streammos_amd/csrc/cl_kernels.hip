@@ -276,6 +276,7 @@ struct GsClArgs {
   const float* scoord;  // [B, N, Ks] or null
   float* out;           // [B, Ho, Wo, *] row pitch op (channel offset applied), zero-filled; or null
   float* pts_out;       // [B, N, *] row pitch po_n (channel offset applied); or null
+  const int32_t* n_live; // device, or null: point rows of the padding tail [*n_live, N) are not wanted (gather_scatter_cl4 only)
   int64_t gp, op, po_b, po_n;
   int B, N, Kg, Ks, Hg, Wg, Ho, Wo;
   float gsy, gsx, ssy, ssx;
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
   float* tile = gs_lds + (kScatter ? (threadIdx.x >> 6) * 64 * kC : 0);      // this wave's [64][kC]
   const int runs_per_sample = (a.N + 63) / 64;
   const int64_t n_runs = (int64_t)a.B * runs_per_sample;
+  const int n_live = a.n_live ? min(max(*a.n_live, 0), a.N) : a.N;
   for (int64_t run = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); run < n_runs; run += (int64_t)gridDim.x * kWavesPerBlock) {
     const int b = (int)(run / runs_per_sample);
     const int n0 = (int)(run - (int64_t)b * runs_per_sample) * 64;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
     const float* gb = a.grid + (int64_t)b * a.Hg * a.Wg * a.gp + 4 * l;
     float* pb = a.pts_out ? a.pts_out + (int64_t)b * a.po_b + (int64_t)n0 * a.po_n + 4 * l : nullptr;
     if (!any_tap) {
-      if (pb) {
+      if (pb && n0 < n_live) {
         for (int i = 0; i < kL; ++i) {
           const int j = grp * kL + i;
           if (n0 + j < a.N) *reinterpret_cast<float4*>(pb + (int64_t)j * a.po_n) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -630,10 +632,25 @@ extern "C" int smos_upsample_concat_cl(const float* const* src, const int64_t* s
   return check_launch("upsample_concat_cl");
 }
 
+extern "C" int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
+                                           const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
+                                           float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
+                                           int64_t N, int64_t Ho, int64_t Wo, const int32_t* n_live, smos_stream_t stream);
+
 extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
                                       const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
                                       float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
                                       int64_t N, int64_t Ho, int64_t Wo, smos_stream_t stream) {
+  return smos_gather_scatter_cl_live(grid, grid_pitch, gcoord, Kg, gscale, scoord, Ks, sscale, out, out_pitch, pts_out, po_b, po_n, B, C,
+                                     Hg, Wg, N, Ho, Wo, nullptr, stream);
+}
+
+// n_live (device int32, may be null): the first *n_live points of every sample are real; point rows of the padding tail that lie
+// wholly outside the source map are not written (they would be zeros nobody reads).  Everything else as smos_gather_scatter_cl.
+extern "C" int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
+                                           const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
+                                           float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
+                                           int64_t N, int64_t Ho, int64_t Wo, const int32_t* n_live, smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && (C == 32 || C == 64) && N > 0 && Hg > 0 && Wg > 0 && Kg >= 2, "gather_scatter_cl: bad sizes (C must be 32 or 64)");
   SMOS_REQUIRE(grid && gcoord && gscale && (out || pts_out) && grid_pitch >= C, "gather_scatter_cl: null pointer / bad pitch");
   SMOS_REQUIRE(!out || (scoord && sscale && Ks >= 2 && Ho > 0 && Wo > 0 && out_pitch >= C && Ho * Wo < (1LL << 31)),
@@ -641,7 +658,7 @@ extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, con
   SMOS_REQUIRE(!pts_out || po_n >= C, "gather_scatter_cl: point row pitch smaller than C");
   SMOS_REQUIRE(Hg * Wg < (1LL << 31), "gather_scatter_cl: grid too large");
   GsClArgs a;
-  a.grid = grid; a.gcoord = gcoord; a.scoord = out ? scoord : nullptr; a.out = out; a.pts_out = pts_out;
+  a.grid = grid; a.gcoord = gcoord; a.scoord = out ? scoord : nullptr; a.out = out; a.pts_out = pts_out; a.n_live = n_live;
   a.gp = grid_pitch; a.op = out_pitch; a.po_b = po_b; a.po_n = po_n;
   a.B = (int)B; a.N = (int)N; a.Kg = Kg; a.Ks = Ks; a.Hg = (int)Hg; a.Wg = (int)Wg; a.Ho = (int)Ho; a.Wo = (int)Wo;
   a.gsy = gscale[0]; a.gsx = gscale[1]; a.ssy = out ? sscale[0] : 0.f; a.ssx = out ? sscale[1] : 0.f;

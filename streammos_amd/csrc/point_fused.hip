@@ -74,6 +74,7 @@ struct PnsArgs {
   float* bev;          // [B, H, W, T*64] zero-filled; or, with row_of, compact rows [n_rows, T*64]
   const int32_t* row_of;  // null, or [B, H, W] row of every occupied cell (csrc/stem.hip): scatter into compact rows
   float* pts_out;      // [B, N, *] rows of the t == 0 sample (row pitch po_n), or null
+  const int32_t* n_live;  // device, or null: points [*n_live, N) of the t == 0 scans are the padding tail: their rows are not wanted
   int64_t bev_sb, po_b, po_n;
   int S, T, N, K, H, W, tiles_per_sample;
 };
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, roff, 0, 0);      // no row table: zero-sized buffer, reads 0
   };
   auto cell_resolve = [&](int c, int r) { return ((a.row_of != nullptr) & (c >= 0)) ? r : c; };
+  const int n_live = a.n_live ? min(max(*a.n_live, 0), a.N) : a.N;
   int nt = (int)blockIdx.x * (kBlock / kWave) + wave_u;
   TileIn cur, nxt;
   fetch(nt, cur);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     const uint32_t tails = (uint32_t)__ballot(hh == 0 && (col == kNt - 1 || cell != cell_after));
     // a tile none of whose points falls into the grid (the padding tail of a scan: 25-40 % of the rows) produces nothing
     // unless its point rows are wanted (t == 0): skip the matrix work, keep the software pipeline moving
-    if (!(a.pts_out && t == 0) && __ballot(cell >= 0) == 0) {
+    if (!(a.pts_out && t == 0 && n0 < n_live) && __ballot(cell >= 0) == 0) {
       // (waited for on this path too: the register copies of the rotation sit in the shared loop latch, and a wait placed
       // there would run on the main path as well -- as a wait for its atomics)
       asm volatile("" : "+v"(nn.x[0]), "+v"(nn.x[1]), "+v"(nn.x[2]), "+v"(nn.x[3]), "+v"(nn.cy), "+v"(nn.cx), "+v"(r_next));
@@ -415,7 +417,7 @@ using namespace smos;
 
 static int pointnet_scatter_launch(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
                                    const float* w2, const float* b2, float* bev, const int32_t* row_of, float* pts_out,
-                                   int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
+                                   const int32_t* n_live, int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
                                    int32_t cmid, int32_t cout, smos_stream_t stream) {
   if (cin != 7 || cmid != 64 || cout != 64) {
     set_error("pointnet_scatter: built for the 7 -> 64 -> 64 point MLP (got %d -> %d -> %d)", (int)cin, (int)cmid, (int)cout);
@@ -428,6 +430,7 @@ static int pointnet_scatter_launch(const float* xyzi, const float* coord, int32_
                "pointnet_scatter: an input larger than 2 GiB (32-bit buffer offsets)");
   PnsArgs a;
   a.xyzi = xyzi; a.coord = coord; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bev = bev; a.row_of = row_of; a.pts_out = pts_out;
+  a.n_live = n_live;
   a.bev_sb = H * W * T * 64; a.po_b = po_b; a.po_n = po_n;
   a.S = (int)(B * T); a.T = (int)T; a.N = (int)N; a.K = K; a.H = (int)H; a.W = (int)W;
   a.tiles_per_sample = (int)((N + kNt - 1) / kNt);
@@ -447,8 +450,8 @@ extern "C" int smos_pointnet_scatter(const float* xyzi, const float* coord, int3
                                      const float* w2, const float* b2, float* bev, float* pts_out, int64_t po_b,
                                      int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W, int32_t cin,
                                      int32_t cmid, int32_t cout, smos_stream_t stream) {
-  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, bev, nullptr, pts_out, po_b, po_n, B, T, N, H, W, cin, cmid, cout,
-                                 stream);
+  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, bev, nullptr, pts_out, nullptr, po_b, po_n, B, T, N, H, W, cin, cmid,
+                                 cout, stream);
 }
 
 extern "C" int smos_pointnet_scatter_rows(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
@@ -456,8 +459,19 @@ extern "C" int smos_pointnet_scatter_rows(const float* xyzi, const float* coord,
                                           int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W,
                                           int32_t cin, int32_t cmid, int32_t cout, smos_stream_t stream) {
   SMOS_REQUIRE(row_of, "pointnet_scatter_rows: null row table");
-  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, rows, row_of, pts_out, po_b, po_n, B, T, N, H, W, cin, cmid, cout,
-                                 stream);
+  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, rows, row_of, pts_out, nullptr, po_b, po_n, B, T, N, H, W, cin, cmid,
+                                 cout, stream);
+}
+
+// n_live (device int32, may be null): the first *n_live points of the current (t == 0) scan of every sample are real; the point
+// rows of its padding tail are not written (nothing reads them once the point head knows the same count).
+extern "C" int smos_pointnet_scatter_rows_live(const float* xyzi, const float* coord, int32_t K, const float* w1, const float* b1,
+                                               const float* w2, const float* b2, float* rows, const int32_t* row_of, float* pts_out,
+                                               int64_t po_b, int64_t po_n, int64_t B, int64_t T, int64_t N, int64_t H, int64_t W,
+                                               int32_t cin, int32_t cmid, int32_t cout, const int32_t* n_live, smos_stream_t stream) {
+  SMOS_REQUIRE(row_of, "pointnet_scatter_rows: null row table");
+  return pointnet_scatter_launch(xyzi, coord, K, w1, b1, w2, b2, rows, row_of, pts_out, n_live, po_b, po_n, B, T, N, H, W, cin, cmid,
+                                 cout, stream);
 }
 
 extern "C" int smos_gather_scatter(const float* grid, const int64_t* grid_stride, const float* gcoord, int32_t Kg,

@@ -367,10 +367,11 @@ class InferenceEngine:
         scoped to the engine's calls instead of flipping the process-wide flag."""
         return torch.backends.cudnn.flags(enabled=True, benchmark=self.miopen_search)
 
-    def encode(self, point_feat, pcds_coord, pcds_sphere_coord):
+    def encode(self, point_feat, pcds_coord, pcds_sphere_coord, n_live=None):
+        """n_live (device int32 tensor, runner only): see decode(); the point rows of the padding tail are not produced."""
         with torch.no_grad(), self._conv_flags():
             if self.layout == "cl":
-                return self._encode_cl(point_feat, pcds_coord, pcds_sphere_coord)
+                return self._encode_cl(point_feat, pcds_coord, pcds_sphere_coord, n_live)
             return self._encode(point_feat, pcds_coord, pcds_sphere_coord)
 
     def decode(self, enc, memory=None, want_aux=True, n_live=None):
@@ -481,7 +482,7 @@ class InferenceEngine:
             x = self._block_cl(x, p, out if i == len(blocks) - 1 else None)
         return x
 
-    def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None):
+    def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None, n_live=None):
         """B2P gather + P2R scatter, range-view convs, R2P gather + P2B scatter straight into cat_buf[:, c:]
         (multi_view_encoder.py:395-405 / :410-420); everything channels-last, nothing transposed."""
         b = cat_buf.shape[0]
@@ -490,7 +491,7 @@ class InferenceEngine:
         rv = self._stage_cl(rv, rv_blocks)
         back = cat_buf[:, c:]
         back.zero_()
-        ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows)
+        ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows, n_live=n_live)
 
     def _stem_sparse_cl(self, bev_cl, pcds_coord):
         """header_bev[0] on the occupied cells of a DENSE channels-last grid (csrc/stem.hip); the engine itself scatters
@@ -498,7 +499,7 @@ class InferenceEngine:
         plan = ops.stem_plan(pcds_coord, bev_cl.shape[1], bev_cl.shape[2])
         return ops.sparse_downsample(bev_cl, plan, self.stem_w, self.header_bev[0].bias, compact=False)
 
-    def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord):
+    def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord, n_live=None):
         bs, t, cin, n, _ = point_feat.shape
         dev = point_feat.device
         bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
@@ -515,7 +516,7 @@ class InferenceEngine:
             # into a compact row table (one row per occupied cell) and the 805 MB dense grid is never built
             plan = ops.stem_plan(pcds_coord, hb, wb, row_floats=t * cpt)
             rows = ops.pointnet_scatter_rows(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1],
-                                             plan, pts_out=fuse[:, :, :o1])
+                                             plan, pts_out=fuse[:, :, :o1], n_live=n_live)
             x = ops.sparse_downsample(rows, plan, self.stem_w, self.header_bev[0].bias, compact=True)
             self._stage_cl(x, self.header_bev[1:], out=x0cat[:, :c0])
         else:
@@ -526,7 +527,7 @@ class InferenceEngine:
         self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
         x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
         self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])
-        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:])
+        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:], n_live=n_live)
         # res2 (the third BEV stage) is independent of the past too, but it runs in decode(): that keeps the two pipeline
         # stages balanced so both HIP streams stay busy (re-measured after the sparse first stage shortened the encoder:
         # res2 on the encode side 158.6 vs 167.5 scans/s)
@@ -557,7 +558,7 @@ class InferenceEngine:
             y = self._conv(dec_in, self.conv_1[0], self.conv_1[1], LEAKY)
             aux = F.conv2d(dec_in, self.aux[0], self.aux[1]) if want_aux else (None, None, None)
         bev_feat = self._conv(y, self.conv_2[0], self.conv_2[1], LEAKY)
-        ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2])
+        ops.gather_scatter_cl(bev_feat, bev_xy, self.grid2point_scale, pts_out=fuse[:, :, o1:o2], n_live=n_live)
         return self._point_heads(fuse, aux, k, x2, n_live)
 
     def _encode(self, point_feat, pcds_coord, pcds_sphere_coord):

@@ -1100,11 +1100,13 @@ def stem_plan(coord, h, w, row_floats=0):
     return StemPlan(b, h, w, row_cell, row_of, meta, rows)
 
 
-def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
+def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None, n_live=None):
     """pointnet_scatter into the COMPACT row table of `plan` (stem_plan(..., row_floats=T*64)): returns plan.rows, a view of
     this stream's scratch (valid until the next plan on the stream); only the first plan.meta[11] rows exist (zero-filled by
     the plan's scan) -- the dense grid is never materialised."""
-    _require_cuda("pointnet_scatter_rows", xyzi, coord, w1, b1, w2, b2, pts_out)
+    _require_cuda("pointnet_scatter_rows", xyzi, coord, w1, b1, w2, b2, pts_out, n_live)
+    if n_live is not None and (n_live.dtype != torch.int32 or n_live.numel() < 1):
+        raise RuntimeError("pointnet_scatter_rows: n_live must be a device int32 tensor")
     b, t, cin, n = xyzi.shape[:4]
     k = coord.shape[3]
     if not (xyzi.is_contiguous() and coord.is_contiguous()):
@@ -1120,11 +1122,12 @@ def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None):
     st = _stream(xyzi)
     # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
     with _on(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
-        rc = lib.smos_pointnet_scatter_rows(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                                            b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
-                                            pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
-                                            plan.h, plan.w, cin, w1.shape[0], cout, st)
-    _lib.check(rc, "smos_pointnet_scatter_rows")
+        rc = lib.smos_pointnet_scatter_rows_live(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                                 b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
+                                                 pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
+                                                 plan.h, plan.w, cin, w1.shape[0], cout,
+                                                 n_live.data_ptr() if n_live is not None else None, st)
+    _lib.check(rc, "smos_pointnet_scatter_rows_live")
     return rows
 
 
@@ -1361,10 +1364,13 @@ def upsample_concat_cl(sources, size):
     return out
 
 
-def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None):
+def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None, n_live=None):
     """grid: channels-last [B,C,Hg,Wg] view; out: channels-last [B,C,Ho,Wo] view, zero-filled (or None);
-    pts_out: [B,N,C] rows (or None)."""
-    _require_cuda("gather_scatter_cl", grid, gcoord, scoord, out, pts_out)
+    pts_out: [B,N,C] rows (or None).  n_live (device int32 tensor, optional): real points at the front of every sample; point
+    rows of the padding tail are not written."""
+    _require_cuda("gather_scatter_cl", grid, gcoord, scoord, out, pts_out, n_live)
+    if n_live is not None and (n_live.dtype != torch.int32 or n_live.numel() < 1):
+        raise RuntimeError("gather_scatter_cl: n_live must be a device int32 tensor")
     b, c, hg, wg = grid.shape
     n, kg = gcoord.shape[1], gcoord.shape[2]
     ho = wo = ks = op = 0
@@ -1377,10 +1383,10 @@ def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, 
     label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d%s]" % (b, c, hg, wg, n, ho, wo,
                                                           "+pts" if pts_out is not None and out is not None else "")
     with _on(grid.device), profiling.span(label):
-        rc = lib.smos_gather_scatter_cl(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
-                                        _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
-                                        _lib.f32_array(sscale) if out is not None else None,
-                                        out.data_ptr() if out is not None else None, op,
-                                        pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, c, hg, wg, n, ho, wo,
-                                        _stream(grid))
-    _lib.check(rc, "smos_gather_scatter_cl")
+        rc = lib.smos_gather_scatter_cl_live(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
+                                             _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
+                                             _lib.f32_array(sscale) if out is not None else None,
+                                             out.data_ptr() if out is not None else None, op,
+                                             pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, c, hg, wg, n, ho, wo,
+                                             n_live.data_ptr() if n_live is not None else None, _stream(grid))
+    _lib.check(rc, "smos_gather_scatter_cl_live")

@@ -455,7 +455,8 @@ class StreamRunner:
             enc = self._pre_enc[1]
             main.wait_stream(self._side)               # encoder of this frame, issued during the previous step
         else:
-            enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
+            enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"],
+                             n_live=dev.get("n_live") if self.skip_padding else None)
         self._pre_enc = None
         if next_dev is not None:                        # encoder of the NEXT frame, concurrent with this decode
             # the side stream must start behind the producers of next_dev.  Inputs made by upload() carry the event
@@ -468,7 +469,8 @@ class StreamRunner:
             else:
                 self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                nxt = eng.encode(next_dev["pcds_xyzi"], next_dev["pcds_coord"], next_dev["pcds_sphere_coord"])
+                nxt = eng.encode(next_dev["pcds_xyzi"], next_dev["pcds_coord"], next_dev["pcds_sphere_coord"],
+                                 n_live=next_dev.get("n_live") if self.skip_padding else None)
             for t in list(nxt.values()) + [next_dev[k] for k in self._KEYS]:
                 if torch.is_tensor(t):
                     t.record_stream(main)
@@ -497,7 +499,8 @@ class StreamRunner:
                     # the same kernels as the pipelined form, one stream: encode, then decode without the three aux heads the
                     # runner never reads (model.infer computes them: 3 GEMMs + 2 resizes per frame that the two-stream step does
                     # not run, so serial traces would not be traces of the timed step)
-                    enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"])
+                    enc = eng.encode(dev["pcds_xyzi"], dev["pcds_coord"], dev["pcds_sphere_coord"],
+                                     n_live=dev.get("n_live") if self.skip_padding else None)
                     res = eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False,
                                      n_live=dev.get("n_live") if self.skip_padding else None)
                 else:
