@@ -26,9 +26,9 @@
 // Weights.  A "pair" P(o, t) = the 16 x 16 block W[16 o .. +16][16 t .. +16] as 64 lanes x float4 (lane (q, m) holds
 // W[16 o + m][16 t + 4 q + 0..3]): one ds_read_b128 per lane feeds 4 MFMAs (128 matrix cycles).  The host packs each
 // layer's weights as the STREAM of pairs in the order the kernel consumes them (ops.tfusion_prepare), cut into slots of 8
-// pairs (8 KB): output_proj o = 0..7 (slot = the 8 k-tiles of an output tile), then for each 16-wide hidden tile j the
-// linear1 slot (its 8 k-tiles) followed by the linear2 slot (hidden tile j as the k-tile of the 8 output tiles), then the
-// next layer's query projection.  All four waves of a block consume the same stream in lock step: slot s + 1 is read from
+// pairs (8 KB): output_proj o = 0..7 (slot = the 8 k-tiles of an output tile), then the FFN one hidden tile of 16 at a time --
+// linear1(0), then linear1(j + 1) and linear2(j) alternating (linear1 slot = the tile's 8 k-tiles, linear2 slot = hidden tile j
+// as the k-tile of the 8 output tiles), linear2(last) -- then the next layer's query projection.  All four waves of a block consume the same stream in lock step: slot s + 1 is read from
 // LDS into registers while the 32 MFMAs of slot s run from registers; slot s + 2 is written to LDS from registers that
 // were loaded from global memory two slots earlier.  Two LDS buffers, one barrier per slot (32 MFMAs = 1 024 matrix
 // cycles).  600 KB of weights per layer stream once per block: 8 B/clk/CU from L2, 32 B/clk/CU from LDS.
@@ -224,28 +224,41 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   }
   layer_norm_tiles(xs, p_g1, p_be1, q, a.eps1);
 
-  // ---- FFN: per hidden tile j: h = relu(W1[j] q1 + b1[j]) (8 pairs, one accumulator), acc2[o] += W2[o][j] h (8 pairs) ----
+  // ---- FFN: per hidden tile j: h_j = relu(W1[j] q1 + b1[j]) (8 pairs, two interleaved accumulators), acc2[o] += W2[o][j] h_j (8
+  //      pairs).  Software-pipelined by one tile: the stream brings linear1(j + 1) BEFORE linear2(j), so that the ReLU of a tile
+  //      is taken a whole slot after its last MFMA was issued (no wait for the matrix result in front of linear2) ----
   tf4 acc2[kTfT];
 #pragma unroll
   for (int o = 0; o < kTfT; ++o) acc2[o] = tf4{0.f, 0.f, 0.f, 0.f};
-  tf4 hacc, hb[1];
-#define TF_ACC_H(p) hacc
+  tf4 hacc[2], hb[1];
+#define TF_ACC_H(p) hacc[(p) >> 2]
 #define TF_ACC_2(p) acc2[p]
 #define TF_B_H(p) hb[0]
+#define TF_H_RELU(j)                                                                   \
+  do {                                                                                 \
+    const float4 b_ = *reinterpret_cast<const float4*>(p_b1 + 16 * (j) + 4 * q);        \
+    hb[0][0] = fmaxf((hacc[0][0] + hacc[1][0]) + b_.x, 0.f);                            \
+    hb[0][1] = fmaxf((hacc[0][1] + hacc[1][1]) + b_.y, 0.f);                            \
+    hb[0][2] = fmaxf((hacc[0][2] + hacc[1][2]) + b_.z, 0.f);                            \
+    hb[0][3] = fmaxf((hacc[0][3] + hacc[1][3]) + b_.w, 0.f);                            \
+    hacc[0] = tf4{0.f, 0.f, 0.f, 0.f};                                                  \
+    hacc[1] = tf4{0.f, 0.f, 0.f, 0.f};                                                  \
+  } while (0)
+  hacc[0] = tf4{0.f, 0.f, 0.f, 0.f};
+  hacc[1] = tf4{0.f, 0.f, 0.f, 0.f};
+  TF_SLOT(0, TF_ACC_H, TF_B_T);                  // linear1(0)
+  TF_H_RELU(0);
 #pragma unroll 1
-  for (int j = 0; j < a.ffn_tiles; ++j) {
-    hacc = tf4{0.f, 0.f, 0.f, 0.f};
-    TF_SLOT(0, TF_ACC_H, TF_B_T);
-    const float4 b = *reinterpret_cast<const float4*>(p_b1 + 16 * j + 4 * q);
-    hb[0][0] = fmaxf(hacc[0] + b.x, 0.f);
-    hb[0][1] = fmaxf(hacc[1] + b.y, 0.f);
-    hb[0][2] = fmaxf(hacc[2] + b.z, 0.f);
-    hb[0][3] = fmaxf(hacc[3] + b.w, 0.f);
-    TF_SLOT(1, TF_ACC_2, TF_B_H);
+  for (int j = 0; j + 1 < a.ffn_tiles; ++j) {
+    TF_SLOT(1, TF_ACC_H, TF_B_T);                // linear1(j + 1) into hacc
+    TF_SLOT(0, TF_ACC_2, TF_B_H);                // linear2(j) from hb
+    TF_H_RELU(j + 1);
   }
+  TF_SLOT(1, TF_ACC_2, TF_B_H);                  // linear2(last)
 #undef TF_ACC_H
 #undef TF_ACC_2
 #undef TF_B_H
+#undef TF_H_RELU
   // + bias + q1 -> LayerNorm 2 -> the layer's output
 #pragma unroll
   for (int t = 0; t < kTfT; ++t) {

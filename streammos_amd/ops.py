@@ -782,8 +782,13 @@ class TfusionLayer:
         dev = wo.device
         po, p1, p2 = _tf_pairs(wo), _tf_pairs(w1), _tf_pairs(w2)          # [8,8,..], [F/16,8,..], [8,F/16,..]
         slots = [po.reshape(8, 8, 64, 4)]
-        ffn_slots = torch.stack((p1, p2.permute(1, 0, 2, 3)), 1)            # [F/16, 2, 8 pairs, 64, 4]: linear1 slot, linear2 slot
-        slots.append(ffn_slots.reshape(-1, 8, 64, 4))
+        # the kernel runs one hidden tile ahead with linear1: linear1(0), then [linear1(j + 1), linear2(j)] ..., linear2(last)
+        l2 = p2.permute(1, 0, 2, 3)                                         # [F/16, 8 output tiles, 64, 4]
+        n_t = ffn // 16
+        slots.append(p1[0:1])
+        if n_t > 1:
+            slots.append(torch.stack((p1[1:], l2[:-1]), 1).reshape(-1, 8, 64, 4))
+        slots.append(l2[-1:])
         self.nq = 0
         bq = torch.zeros(64, dtype=torch.float32, device=dev)
         if next_qproj is not None:
