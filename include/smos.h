@@ -251,13 +251,13 @@ int smos_msda_fwd_qp(const float* value, const float* qp, float* out, int64_t N,
  * smos_tfusion_project: up to four token-wise Linear jobs y = W x + b in one launch -- the projections of a frame that depend on
  *   no previous layer (value_proj of every layer, the first layer's [sampling_offsets | attention_weights]).  Host arrays
  *   of n_jobs entries; x[j] [tokens, *] rows of pitch x_pitch[j] floats (>= 128); wstream[j] = the weights as 16 x 16
- *   blocks in MFMA operand order (streammos_amd.ops.tfusion_pack_linear: cout rounded up to a multiple of 32, zero
+ *   blocks in MFMA operand order (streammos_amd.ops.tfusion_pack_linear: cout rounded up to a multiple of 64, zero
  *   padded); bias[j] [cout]; out[j] [tokens, cout] dense; cout a multiple of 4, <= 256.
  * smos_tfusion_layer: everything of one layer behind its sampler in one launch:
  *   q1 = norm1(query + output_proj(sampled)); out = norm2(q1 + linear2(relu(linear1(q1)))); and, if qp_next != NULL,
  *   qp_next = W_q out + b_q -- the NEXT layer's offset / logit projection (nq <= 64 channels), so that the following
  *   smos_msda_fwd_qp can start at once.  wstream / params = streammos_amd.ops.TfusionLayer (sizes:
- *   smos_tfusion_layer_stream_floats / _param_floats); ffn a multiple of 16. */
+ *   smos_tfusion_layer_stream_floats / _param_floats); ffn a multiple of 32. */
 int smos_tfusion_project(int32_t n_jobs, const float* const* x, const int64_t* x_pitch, const float* const* wstream,
                          const float* const* bias, float* const* out, const int64_t* cout, int64_t tokens, smos_stream_t stream);
 int64_t smos_tfusion_layer_param_floats(int64_t ffn);

@@ -47,11 +47,11 @@ constexpr int kTfT = kTfC / 16;        // k-tiles / output tiles of a 128-wide l
 constexpr int kTfSlot = 8 * 64;        // float4 per slot: 8 pairs x 64 lanes
 constexpr int kTfSlotBytes = kTfSlot * 16;
 
-// ---- the weight stream: global -> registers (two slots in flight) -> LDS (two buffers) -> fragment registers ----
+// ---- the weight stream: global -> registers (four slots in flight) -> LDS (two buffers) -> fragment registers ----
 struct TfStream {
   __amdgpu_buffer_rsrc_t srd;
   unsigned next;        // byte offset of the next slot to request (this thread's first float4 of it)
-  u32x4 g[2][2];        // staging registers: set = slot parity
+  u32x4 g[4][2];        // staging registers: set = slot index & 3
 };
 
 #define TF_GLOAD(st, set)                                                                        \
@@ -70,8 +70,9 @@ struct TfStream {
   } while (0)
 
 // One slot: barrier (slot s + 1 visible, everybody done with the buffer slot s + 2 goes to), then per pair p: read pair p
-// of slot s + 1 into the other fragment set and run the four MFMAs of pair p of slot s (PAIR(p) names accumulator and B
-// tile); then park slot s + 2 and request slot s + 4.  PAR = s & 1 (compile-time).
+// of slot s + 1 into the other fragment set and run the four MFMAs of pair p of slot s (ACC_OF / B_OF name accumulator and B
+// tile); then park slot s + 2 and request slot s + 6 (four slots = 4 x 1 024 matrix cycles in flight: an L2 hit takes longer
+// than two).  IDX = s & 3 (compile-time): fragment set and LDS buffer = IDX & 1, staging set of slot s + 2 = (IDX + 2) & 3.
 #define TF_MFMA4(accv, frag, bt)                                                                 \
   do {                                                                                           \
     accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).x, (bt)[0], accv, 0, 0, 0);               \
@@ -79,25 +80,27 @@ struct TfStream {
     accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).z, (bt)[2], accv, 0, 0, 0);               \
     accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).w, (bt)[3], accv, 0, 0, 0);               \
   } while (0)
-#define TF_SLOT(PAR, ACC_OF, B_OF)                                                               \
+#define TF_SLOT(IDX, ACC_OF, B_OF)                                                               \
   do {                                                                                           \
     ring_barrier();                                                                              \
-    const float4* rd_ = ring + ((PAR) ^ 1) * kTfSlot + lane;                                     \
+    const float4* rd_ = ring + (((IDX) & 1) ^ 1) * kTfSlot + lane;                               \
     _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                           \
-      frag[(PAR) ^ 1][p_] = rd_[p_ * 64];                                                        \
-      TF_MFMA4(ACC_OF(p_), frag[PAR][p_], B_OF(p_));                                             \
+      frag[((IDX) & 1) ^ 1][p_] = rd_[p_ * 64];                                                  \
+      TF_MFMA4(ACC_OF(p_), frag[(IDX) & 1][p_], B_OF(p_));                                       \
     }                                                                                            \
-    TF_PARK(st, PAR, ring + (PAR) * kTfSlot);                                                    \
-    TF_GLOAD(st, PAR);                                                                           \
+    TF_PARK(st, ((IDX) + 2) & 3, ring + ((IDX) & 1) * kTfSlot);                                  \
+    TF_GLOAD(st, ((IDX) + 2) & 3);                                                               \
   } while (0)
 
-// prologue of a stream: slots 0 and 1 parked, slots 2 and 3 in flight, fragments of slot 0 in frag[0]
+// prologue of a stream: slots 0 and 1 parked, slots 2 .. 5 in flight, fragments of slot 0 in frag[0]
 #define TF_STREAM_BEGIN(wptr, wbytes)                                                            \
   do {                                                                                           \
     st.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wptr), 0, (int)(wbytes), 0x00020000); \
     st.next = threadIdx.x * 16u;                                                                 \
     TF_GLOAD(st, 0);                                                                             \
     TF_GLOAD(st, 1);                                                                             \
+    TF_GLOAD(st, 2);                                                                             \
+    TF_GLOAD(st, 3);                                                                             \
     TF_PARK(st, 0, ring);                                                                        \
     TF_GLOAD(st, 0);                                                                             \
     TF_PARK(st, 1, ring + kTfSlot);                                                              \
@@ -206,11 +209,17 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
 #define TF_ACC_OA(p) acc1[o_]
 #define TF_ACC_OB(p) acc1[o_ + 1]
 #define TF_B_T(p) xs[p]
+#define TF_ACC_OC(p) acc1[o_ + 2]
+#define TF_ACC_OD(p) acc1[o_ + 3]
 #pragma unroll
-  for (int o_ = 0; o_ < kTfT; o_ += 2) {
+  for (int o_ = 0; o_ < kTfT; o_ += 4) {
     TF_SLOT(0, TF_ACC_OA, TF_B_T);
     TF_SLOT(1, TF_ACC_OB, TF_B_T);
+    TF_SLOT(2, TF_ACC_OC, TF_B_T);
+    TF_SLOT(3, TF_ACC_OD, TF_B_T);
   }
+#undef TF_ACC_OC
+#undef TF_ACC_OD
 #undef TF_ACC_OA
 #undef TF_ACC_OB
   // + bias + query -> LayerNorm 1 -> q1 (kept in xs: linear1's B operand and the second residual)
@@ -249,12 +258,18 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   TF_SLOT(0, TF_ACC_H, TF_B_T);                  // linear1(0)
   TF_H_RELU(0);
 #pragma unroll 1
-  for (int j = 0; j + 1 < a.ffn_tiles; ++j) {
+  for (int j = 0; j + 2 < a.ffn_tiles; j += 2) {   // ffn_tiles is even (host check): slot index & 3 is static
     TF_SLOT(1, TF_ACC_H, TF_B_T);                // linear1(j + 1) into hacc
-    TF_SLOT(0, TF_ACC_2, TF_B_H);                // linear2(j) from hb
+    TF_SLOT(2, TF_ACC_2, TF_B_H);                // linear2(j) from hb
     TF_H_RELU(j + 1);
+    TF_SLOT(3, TF_ACC_H, TF_B_T);                // linear1(j + 2)
+    TF_SLOT(0, TF_ACC_2, TF_B_H);                // linear2(j + 1)
+    TF_H_RELU(j + 2);
   }
-  TF_SLOT(1, TF_ACC_2, TF_B_H);                  // linear2(last)
+  TF_SLOT(1, TF_ACC_H, TF_B_T);                  // linear1(last)
+  TF_SLOT(2, TF_ACC_2, TF_B_H);                  // linear2(last - 1)
+  TF_H_RELU(a.ffn_tiles - 1);
+  TF_SLOT(3, TF_ACC_2, TF_B_H);                  // linear2(last)
 #undef TF_ACC_H
 #undef TF_ACC_2
 #undef TF_B_H
@@ -287,8 +302,8 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
 #define TF_ACC_Q3(p) accq[3]
     TF_SLOT(0, TF_ACC_Q0, TF_B_T);
     TF_SLOT(1, TF_ACC_Q1, TF_B_T);
-    TF_SLOT(0, TF_ACC_Q2, TF_B_T);
-    TF_SLOT(1, TF_ACC_Q3, TF_B_T);
+    TF_SLOT(2, TF_ACC_Q2, TF_B_T);
+    TF_SLOT(3, TF_ACC_Q3, TF_B_T);
 #undef TF_ACC_Q0
 #undef TF_ACC_Q1
 #undef TF_ACC_Q2
@@ -310,11 +325,11 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 struct TfJob {
   const float* x;          // [tokens, *] pitch xp
-  const float4* wstream;   // tiles_padded slots (tiles rounded up to even): slot o = P(o, t = 0..7)
+  const float4* wstream;   // tiles slots (cout rounded up to a multiple of 64): slot o = P(o, t = 0..7)
   const float* bias;       // [cout]
   float* out;              // [tokens, cout] dense rows
   int64_t xp;
-  int cout, tiles;         // channels stored; slots streamed (even)
+  int cout, tiles;         // channels stored; slots streamed (a multiple of 4)
 };
 struct TfProjectArgs {
   TfJob job[4];
@@ -350,13 +365,19 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
     __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc + b_), osrd, off_, 0, 0);                                      \
   } while (0)
 #pragma unroll 1
-  for (int o = 0; o < jb.tiles; o += 2) {
+  for (int o = 0; o < jb.tiles; o += 4) {
     acc = tf4{0.f, 0.f, 0.f, 0.f};
     TF_SLOT(0, TF_ACC_P, TF_B_T);
     TF_EMIT(o);
     acc = tf4{0.f, 0.f, 0.f, 0.f};
     TF_SLOT(1, TF_ACC_P, TF_B_T);
     TF_EMIT(o + 1);
+    acc = tf4{0.f, 0.f, 0.f, 0.f};
+    TF_SLOT(2, TF_ACC_P, TF_B_T);
+    TF_EMIT(o + 2);
+    acc = tf4{0.f, 0.f, 0.f, 0.f};
+    TF_SLOT(3, TF_ACC_P, TF_B_T);
+    TF_EMIT(o + 3);
   }
 #undef TF_ACC_P
 #undef TF_B_T
@@ -370,7 +391,7 @@ using namespace smos;
 // Token-wise Linear layers y = W x + b on 128-channel token rows, up to four jobs in one launch (the projections of a frame's
 // temporal fusion that do not depend on a previous layer: value_proj of every DeformAttnLayer and the first layer's
 // [sampling_offsets | attention_weights], deformattn/modules/ms_deform_attn.py:94-103).  Per job: x [tokens, *] (row pitch
-// x_pitch floats, >= 128), wstream = ops.tfusion_pack_linear(W) (cout rounded up to a multiple of 32, zero padded), bias
+// x_pitch floats, >= 128), wstream = ops.tfusion_pack_linear(W) (cout rounded up to a multiple of 64, zero padded), bias
 // [cout], out [tokens, cout] dense.  cout a multiple of 4, <= 256.
 extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const int64_t* x_pitch, const float* const* wstream,
                                     const float* const* bias, float* const* out, const int64_t* cout, int64_t tokens,
@@ -385,7 +406,7 @@ extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const
                    reinterpret_cast<uintptr_t>(out[j])) & 15) == 0, "tfusion_project: pointers must be 16-byte aligned");
     SMOS_REQUIRE(tokens * x_pitch[j] * 4 < (1LL << 31), "tfusion_project: input larger than 2 GiB");
     a.job[j].x = x[j]; a.job[j].wstream = reinterpret_cast<const float4*>(wstream[j]); a.job[j].bias = bias[j]; a.job[j].out = out[j];
-    a.job[j].xp = x_pitch[j]; a.job[j].cout = (int)cout[j]; a.job[j].tiles = (int)((cout[j] + 31) / 32 * 2);
+    a.job[j].xp = x_pitch[j]; a.job[j].cout = (int)cout[j]; a.job[j].tiles = (int)((cout[j] + 63) / 64 * 4);
   }
   for (int j = n_jobs; j < 4; ++j) a.job[j] = a.job[0];
   const size_t lds = (size_t)2 * kTfSlotBytes;
@@ -407,7 +428,7 @@ extern "C" int64_t smos_tfusion_layer_stream_floats(int64_t ffn, int32_t has_nex
 extern "C" int smos_tfusion_layer(const float* sampled, const float* query, int64_t q_pitch, const float* wstream, const float* params,
                                   float* out, int64_t o_pitch, float* qp_next, int64_t nq, int64_t tokens, int64_t ffn, float eps1,
                                   float eps2, smos_stream_t stream) {
-  SMOS_REQUIRE(tokens > 0 && tokens < (1LL << 22) && ffn >= 16 && ffn % 16 == 0 && ffn <= 4096, "tfusion_layer: bad sizes");
+  SMOS_REQUIRE(tokens > 0 && tokens < (1LL << 22) && ffn >= 32 && ffn % 32 == 0 && ffn <= 4096, "tfusion_layer: bad sizes (ffn a multiple of 32)");
   SMOS_REQUIRE(sampled && query && wstream && params && out && q_pitch >= kTfC && o_pitch >= kTfC && q_pitch % 4 == 0 &&
                    o_pitch % 4 == 0, "tfusion_layer: null pointer / bad pitch");
   SMOS_REQUIRE(!qp_next || (nq > 0 && nq <= 64 && nq % 4 == 0), "tfusion_layer: the next projection has 4..64 channels");

@@ -757,12 +757,12 @@ def _tf_pairs(w):
 
 
 def tfusion_pack_linear(w):
-    """w [cout, 128] -> the weight stream of one smos_tfusion_project job: cout zero-padded to a multiple of 32, slot o = the
+    """w [cout, 128] -> the weight stream of one smos_tfusion_project job: cout zero-padded to a multiple of 64, slot o = the
     eight pairs (o, t = 0..7)."""
     cout, k = w.shape
     if k != 128 or cout > 256:
         raise RuntimeError("tfusion_pack_linear: expected [<=256, 128], got %s" % (tuple(w.shape),))
-    pad = (cout + 31) // 32 * 32
+    pad = (cout + 63) // 64 * 64
     wp = torch.zeros((pad, k), dtype=torch.float32, device=w.device)
     wp[:cout] = w
     return _tf_pairs(wp).reshape(-1).contiguous()
@@ -777,8 +777,8 @@ class TfusionLayer:
         w1, b1 = lin1
         w2, b2 = lin2
         ffn = w1.shape[0]
-        if tuple(wo.shape) != (128, 128) or w1.shape[1] != 128 or tuple(w2.shape) != (128, ffn) or ffn % 16:
-            raise RuntimeError("TfusionLayer: built for d_model 128 and an FFN width that is a multiple of 16")
+        if tuple(wo.shape) != (128, 128) or w1.shape[1] != 128 or tuple(w2.shape) != (128, ffn) or ffn % 32:
+            raise RuntimeError("TfusionLayer: built for d_model 128 and an FFN width that is a multiple of 32")
         dev = wo.device
         po, p1, p2 = _tf_pairs(wo), _tf_pairs(w1), _tf_pairs(w2)          # [8,8,..], [F/16,8,..], [8,F/16,..]
         slots = [po.reshape(8, 8, 64, 4)]
@@ -840,7 +840,7 @@ def tfusion_project(jobs):
             raise RuntimeError("tfusion_project: every job reads the same number of 128-channel token rows")
         tokens = tk
         cout = int(b.shape[0])
-        if w.numel() != (cout + 31) // 32 * 32 * 128:
+        if w.numel() != (cout + 63) // 64 * 64 * 128:
             raise RuntimeError("tfusion_project: weight stream of %d floats for %d outputs" % (w.numel(), cout))
         out = torch.empty((tokens, cout), dtype=torch.float32, device=x.device)
         res.append(out)
