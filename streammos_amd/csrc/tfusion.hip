@@ -73,23 +73,50 @@ struct TfStream {
 // of slot s + 1 into the other fragment set and run the four MFMAs of pair p of slot s (ACC_OF / B_OF name accumulator and B
 // tile); then park slot s + 2 and request slot s + 6 (four slots = 4 x 1 024 matrix cycles in flight: an L2 hit takes longer
 // than two).  IDX = s & 3 (compile-time): fragment set and LDS buffer = IDX & 1, staging set of slot s + 2 = (IDX + 2) & 3.
-#define TF_MFMA4(accv, frag, bt)                                                                 \
+// (v_mfma_f32_16x16x4_f32 issues every 32 cycles but a DEPENDENT one needs 40: consecutive MFMAs never share an accumulator.)
+// ROW slot: all eight pairs accumulate ONE output tile (output_proj, linear1, the projections): the k sum is split over two
+// accumulators by the parity of r, consecutive MFMAs alternate between them; the caller adds the two.
+#define TF_SLOT_HEAD(IDX)                                                                        \
+  ring_barrier();                                                                                \
+  const float4* rd_ = ring + (((IDX) & 1) ^ 1) * kTfSlot + lane
+#define TF_SLOT_TAIL(IDX)                                                                        \
+  TF_PARK(st, ((IDX) + 2) & 3, ring + ((IDX) & 1) * kTfSlot);                                    \
+  TF_GLOAD(st, ((IDX) + 2) & 3)
+#define TF_SLOT_ROW(IDX, EA, EB, B_OF)                                                           \
   do {                                                                                           \
-    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).x, (bt)[0], accv, 0, 0, 0);               \
-    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).y, (bt)[1], accv, 0, 0, 0);               \
-    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).z, (bt)[2], accv, 0, 0, 0);               \
-    accv = __builtin_amdgcn_mfma_f32_16x16x4f32((frag).w, (bt)[3], accv, 0, 0, 0);               \
-  } while (0)
-#define TF_SLOT(IDX, ACC_OF, B_OF)                                                               \
-  do {                                                                                           \
-    ring_barrier();                                                                              \
-    const float4* rd_ = ring + (((IDX) & 1) ^ 1) * kTfSlot + lane;                               \
+    TF_SLOT_HEAD(IDX);                                                                           \
     _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                           \
       frag[((IDX) & 1) ^ 1][p_] = rd_[p_ * 64];                                                  \
-      TF_MFMA4(ACC_OF(p_), frag[(IDX) & 1][p_], B_OF(p_));                                       \
+      const float4 f_ = frag[(IDX) & 1][p_];                                                     \
+      EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.x, B_OF(p_)[0], EA, 0, 0, 0);                 \
+      EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.y, B_OF(p_)[1], EB, 0, 0, 0);                 \
+      EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.z, B_OF(p_)[2], EA, 0, 0, 0);                 \
+      EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.w, B_OF(p_)[3], EB, 0, 0, 0);                 \
     }                                                                                            \
-    TF_PARK(st, ((IDX) + 2) & 3, ring + ((IDX) & 1) * kTfSlot);                                  \
-    TF_GLOAD(st, ((IDX) + 2) & 3);                                                               \
+    TF_SLOT_TAIL(IDX);                                                                           \
+  } while (0)
+// COLUMN slot: pair p accumulates output tile p from ONE B tile (linear2): r-major, so that the eight MFMAs of an r go to eight
+// different accumulators.
+#define TF_SLOT_COL(IDX, ACC_OF, BT)                                                             \
+  do {                                                                                           \
+    TF_SLOT_HEAD(IDX);                                                                           \
+    frag[((IDX) & 1) ^ 1][0] = rd_[0 * 64];                                                      \
+    frag[((IDX) & 1) ^ 1][1] = rd_[1 * 64];                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
+        ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].x, (BT)[0], ACC_OF(p_), 0, 0, 0); \
+    frag[((IDX) & 1) ^ 1][2] = rd_[2 * 64];                                                      \
+    frag[((IDX) & 1) ^ 1][3] = rd_[3 * 64];                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
+        ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].y, (BT)[1], ACC_OF(p_), 0, 0, 0); \
+    frag[((IDX) & 1) ^ 1][4] = rd_[4 * 64];                                                      \
+    frag[((IDX) & 1) ^ 1][5] = rd_[5 * 64];                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
+        ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].z, (BT)[2], ACC_OF(p_), 0, 0, 0); \
+    frag[((IDX) & 1) ^ 1][6] = rd_[6 * 64];                                                      \
+    frag[((IDX) & 1) ^ 1][7] = rd_[7 * 64];                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
+        ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].w, (BT)[3], ACC_OF(p_), 0, 0, 0); \
+    TF_SLOT_TAIL(IDX);                                                                           \
   } while (0)
 
 // prologue of a stream: slots 0 and 1 parked, slots 2 .. 5 in flight, fragments of slot 0 in frag[0]
@@ -203,25 +230,23 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   TF_STREAM_BEGIN(a.wstream, a.w_bytes);           // its barrier also publishes prm
 
   // ---- output_proj: acc1[o] = sum_t P(o, t) xs[t] ----
-  tf4 acc1[kTfT];
-#pragma unroll
-  for (int o = 0; o < kTfT; ++o) acc1[o] = tf4{0.f, 0.f, 0.f, 0.f};
-#define TF_ACC_OA(p) acc1[o_]
-#define TF_ACC_OB(p) acc1[o_ + 1]
+  tf4 acc1[kTfT], ea, eb;
+  const tf4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define TF_B_T(p) xs[p]
-#define TF_ACC_OC(p) acc1[o_ + 2]
-#define TF_ACC_OD(p) acc1[o_ + 3]
+#define TF_ROW_OUT(IDX, dst)            \
+  do {                                  \
+    ea = zero4;                         \
+    eb = zero4;                         \
+    TF_SLOT_ROW(IDX, ea, eb, TF_B_T);   \
+    dst = ea + eb;                      \
+  } while (0)
 #pragma unroll
   for (int o_ = 0; o_ < kTfT; o_ += 4) {
-    TF_SLOT(0, TF_ACC_OA, TF_B_T);
-    TF_SLOT(1, TF_ACC_OB, TF_B_T);
-    TF_SLOT(2, TF_ACC_OC, TF_B_T);
-    TF_SLOT(3, TF_ACC_OD, TF_B_T);
+    TF_ROW_OUT(0, acc1[o_]);
+    TF_ROW_OUT(1, acc1[o_ + 1]);
+    TF_ROW_OUT(2, acc1[o_ + 2]);
+    TF_ROW_OUT(3, acc1[o_ + 3]);
   }
-#undef TF_ACC_OC
-#undef TF_ACC_OD
-#undef TF_ACC_OA
-#undef TF_ACC_OB
   // + bias + query -> LayerNorm 1 -> q1 (kept in xs: linear1's B operand and the second residual)
 #pragma unroll
   for (int t = 0; t < kTfT; ++t) {
@@ -239,40 +264,32 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   tf4 acc2[kTfT];
 #pragma unroll
   for (int o = 0; o < kTfT; ++o) acc2[o] = tf4{0.f, 0.f, 0.f, 0.f};
-  tf4 hacc[2], hb[1];
-#define TF_ACC_H(p) hacc[(p) >> 2]
+  tf4 hsum, hb;
 #define TF_ACC_2(p) acc2[p]
-#define TF_B_H(p) hb[0]
 #define TF_H_RELU(j)                                                                   \
   do {                                                                                 \
     const float4 b_ = *reinterpret_cast<const float4*>(p_b1 + 16 * (j) + 4 * q);        \
-    hb[0][0] = fmaxf((hacc[0][0] + hacc[1][0]) + b_.x, 0.f);                            \
-    hb[0][1] = fmaxf((hacc[0][1] + hacc[1][1]) + b_.y, 0.f);                            \
-    hb[0][2] = fmaxf((hacc[0][2] + hacc[1][2]) + b_.z, 0.f);                            \
-    hb[0][3] = fmaxf((hacc[0][3] + hacc[1][3]) + b_.w, 0.f);                            \
-    hacc[0] = tf4{0.f, 0.f, 0.f, 0.f};                                                  \
-    hacc[1] = tf4{0.f, 0.f, 0.f, 0.f};                                                  \
+    hb[0] = fmaxf(hsum[0] + b_.x, 0.f);                                                 \
+    hb[1] = fmaxf(hsum[1] + b_.y, 0.f);                                                 \
+    hb[2] = fmaxf(hsum[2] + b_.z, 0.f);                                                 \
+    hb[3] = fmaxf(hsum[3] + b_.w, 0.f);                                                 \
   } while (0)
-  hacc[0] = tf4{0.f, 0.f, 0.f, 0.f};
-  hacc[1] = tf4{0.f, 0.f, 0.f, 0.f};
-  TF_SLOT(0, TF_ACC_H, TF_B_T);                  // linear1(0)
+  TF_ROW_OUT(0, hsum);                           // linear1(0)
   TF_H_RELU(0);
 #pragma unroll 1
   for (int j = 0; j + 2 < a.ffn_tiles; j += 2) {   // ffn_tiles is even (host check): slot index & 3 is static
-    TF_SLOT(1, TF_ACC_H, TF_B_T);                // linear1(j + 1) into hacc
-    TF_SLOT(2, TF_ACC_2, TF_B_H);                // linear2(j) from hb
+    TF_ROW_OUT(1, hsum);                         // linear1(j + 1)
+    TF_SLOT_COL(2, TF_ACC_2, hb);                // linear2(j) from hb
     TF_H_RELU(j + 1);
-    TF_SLOT(3, TF_ACC_H, TF_B_T);                // linear1(j + 2)
-    TF_SLOT(0, TF_ACC_2, TF_B_H);                // linear2(j + 1)
+    TF_ROW_OUT(3, hsum);                         // linear1(j + 2)
+    TF_SLOT_COL(0, TF_ACC_2, hb);                // linear2(j + 1)
     TF_H_RELU(j + 2);
   }
-  TF_SLOT(1, TF_ACC_H, TF_B_T);                  // linear1(last)
-  TF_SLOT(2, TF_ACC_2, TF_B_H);                  // linear2(last - 1)
+  TF_ROW_OUT(1, hsum);                           // linear1(last)
+  TF_SLOT_COL(2, TF_ACC_2, hb);                  // linear2(last - 1)
   TF_H_RELU(a.ffn_tiles - 1);
-  TF_SLOT(3, TF_ACC_2, TF_B_H);                  // linear2(last)
-#undef TF_ACC_H
+  TF_SLOT_COL(3, TF_ACC_2, hb);                  // linear2(last)
 #undef TF_ACC_2
-#undef TF_B_H
 #undef TF_H_RELU
   // + bias + q1 -> LayerNorm 2 -> the layer's output
 #pragma unroll
@@ -294,20 +311,10 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   // ---- the next layer's offset / logit projection on the fresh output (4 slots: up to 64 channels, nq stored) ----
   if (a.qp_next) {
     tf4 accq[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) accq[o] = tf4{0.f, 0.f, 0.f, 0.f};
-#define TF_ACC_Q0(p) accq[0]
-#define TF_ACC_Q1(p) accq[1]
-#define TF_ACC_Q2(p) accq[2]
-#define TF_ACC_Q3(p) accq[3]
-    TF_SLOT(0, TF_ACC_Q0, TF_B_T);
-    TF_SLOT(1, TF_ACC_Q1, TF_B_T);
-    TF_SLOT(2, TF_ACC_Q2, TF_B_T);
-    TF_SLOT(3, TF_ACC_Q3, TF_B_T);
-#undef TF_ACC_Q0
-#undef TF_ACC_Q1
-#undef TF_ACC_Q2
-#undef TF_ACC_Q3
+    TF_ROW_OUT(0, accq[0]);
+    TF_ROW_OUT(1, accq[1]);
+    TF_ROW_OUT(2, accq[2]);
+    TF_ROW_OUT(3, accq[3]);
     const __amdgpu_buffer_rsrc_t nsrd = __builtin_amdgcn_make_buffer_rsrc(a.qp_next, 0, a.tokens * a.nq * 4, 0x00020000);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
     }
   }
 #undef TF_B_T
+#undef TF_ROW_OUT
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -355,7 +363,8 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
   TfStream st;
   float4 frag[2][8];
   TF_STREAM_BEGIN(jb.wstream, jb.tiles * kTfSlotBytes);
-  tf4 acc;
+  tf4 acc, ea, eb;
+  const tf4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define TF_ACC_P(p) acc
 #define TF_B_T(p) xs[p]
 #define TF_EMIT(o)                                                                                                     \
@@ -364,21 +373,22 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
     const unsigned off_ = (live && 16 * (o) + 4 * q < jb.cout) ? (unsigned)(row * jb.cout + 16 * (o) + 4 * q) * 4u : 0x80000000u; \
     __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc + b_), osrd, off_, 0, 0);                                      \
   } while (0)
+#define TF_ROW_EMIT(IDX, o)             \
+  do {                                  \
+    ea = zero4;                         \
+    eb = zero4;                         \
+    TF_SLOT_ROW(IDX, ea, eb, TF_B_T);   \
+    acc = ea + eb;                      \
+    TF_EMIT(o);                         \
+  } while (0)
 #pragma unroll 1
   for (int o = 0; o < jb.tiles; o += 4) {
-    acc = tf4{0.f, 0.f, 0.f, 0.f};
-    TF_SLOT(0, TF_ACC_P, TF_B_T);
-    TF_EMIT(o);
-    acc = tf4{0.f, 0.f, 0.f, 0.f};
-    TF_SLOT(1, TF_ACC_P, TF_B_T);
-    TF_EMIT(o + 1);
-    acc = tf4{0.f, 0.f, 0.f, 0.f};
-    TF_SLOT(2, TF_ACC_P, TF_B_T);
-    TF_EMIT(o + 2);
-    acc = tf4{0.f, 0.f, 0.f, 0.f};
-    TF_SLOT(3, TF_ACC_P, TF_B_T);
-    TF_EMIT(o + 3);
+    TF_ROW_EMIT(0, o);
+    TF_ROW_EMIT(1, o + 1);
+    TF_ROW_EMIT(2, o + 2);
+    TF_ROW_EMIT(3, o + 3);
   }
+#undef TF_ROW_EMIT
 #undef TF_ACC_P
 #undef TF_B_T
 #undef TF_EMIT
