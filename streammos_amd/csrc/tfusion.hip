@@ -38,6 +38,18 @@
 // (tests/test_gpu_ops.py::test_tfusion_*).
 #include "conv_common.h"
 
+// Diagnostic build only (tools/tf_stamps.py, -DSMOS_TF_STAMPS): s_memtime stamps of wave 0 of every block at the phase
+// borders of tfusion_layer, written to the buffer whose address the script passes in SMOS_TF_STAMP_PTR.
+#ifdef SMOS_TF_STAMPS
+#include <stdlib.h>
+#define TF_STAMP(k)                                                                             \
+  do {                                                                                          \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TF_STAMP(k) ((void)0)
+#endif
+
 namespace smos {
 
 typedef float tf4 __attribute__((ext_vector_type(4)));
@@ -82,18 +94,26 @@ struct TfStream {
 #define TF_SLOT_TAIL(IDX)                                                                        \
   TF_PARK(st, ((IDX) + 2) & 3, ring + ((IDX) & 1) * kTfSlot);                                    \
   TF_GLOAD(st, ((IDX) + 2) & 3)
+#define TF_ROW_PAIR(IDX, EA, EB, B_OF, p_)                                                      \
+  do {                                                                                           \
+    frag[((IDX) & 1) ^ 1][p_] = rd_[(p_) * 64];                                                  \
+    const float4 f_ = frag[(IDX) & 1][p_];                                                       \
+    EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.x, B_OF(p_)[0], EA, 0, 0, 0);                   \
+    EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.y, B_OF(p_)[1], EB, 0, 0, 0);                   \
+    EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.z, B_OF(p_)[2], EA, 0, 0, 0);                   \
+    EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.w, B_OF(p_)[3], EB, 0, 0, 0);                   \
+  } while (0)
+// (the park + request sit EARLY in the slot: at its end the LDS writes would still be in flight at the next slot's barrier,
+// whose s_waitcnt lgkmcnt(0) then exposes their latency once per slot)
 #define TF_SLOT_ROW(IDX, EA, EB, B_OF)                                                           \
   do {                                                                                           \
     TF_SLOT_HEAD(IDX);                                                                           \
-    _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                           \
-      frag[((IDX) & 1) ^ 1][p_] = rd_[p_ * 64];                                                  \
-      const float4 f_ = frag[(IDX) & 1][p_];                                                     \
-      EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.x, B_OF(p_)[0], EA, 0, 0, 0);                 \
-      EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.y, B_OF(p_)[1], EB, 0, 0, 0);                 \
-      EA = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.z, B_OF(p_)[2], EA, 0, 0, 0);                 \
-      EB = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.w, B_OF(p_)[3], EB, 0, 0, 0);                 \
-    }                                                                                            \
+    TF_ROW_PAIR(IDX, EA, EB, B_OF, 0);                                                           \
+    TF_ROW_PAIR(IDX, EA, EB, B_OF, 1);                                                           \
+    SMOS_FENCE();                                                                                \
     TF_SLOT_TAIL(IDX);                                                                           \
+    SMOS_FENCE();                                                                                \
+    _Pragma("unroll") for (int p_ = 2; p_ < 8; ++p_) TF_ROW_PAIR(IDX, EA, EB, B_OF, p_);         \
   } while (0)
 // COLUMN slot: pair p accumulates output tile p from ONE B tile (linear2): r-major, so that the eight MFMAs of an r go to eight
 // different accumulators.
@@ -104,6 +124,9 @@ struct TfStream {
     frag[((IDX) & 1) ^ 1][1] = rd_[1 * 64];                                                      \
     _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
         ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].x, (BT)[0], ACC_OF(p_), 0, 0, 0); \
+    SMOS_FENCE();                                                                                \
+    TF_SLOT_TAIL(IDX);                                                                           \
+    SMOS_FENCE();                                                                                \
     frag[((IDX) & 1) ^ 1][2] = rd_[2 * 64];                                                      \
     frag[((IDX) & 1) ^ 1][3] = rd_[3 * 64];                                                      \
     _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
@@ -116,11 +139,12 @@ struct TfStream {
     frag[((IDX) & 1) ^ 1][7] = rd_[7 * 64];                                                      \
     _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_)                                             \
         ACC_OF(p_) = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[(IDX) & 1][p_].w, (BT)[3], ACC_OF(p_), 0, 0, 0); \
-    TF_SLOT_TAIL(IDX);                                                                           \
   } while (0)
 
-// prologue of a stream: slots 0 and 1 parked, slots 2 .. 5 in flight, fragments of slot 0 in frag[0]
-#define TF_STREAM_BEGIN(wptr, wbytes)                                                            \
+// prologue of a stream, in two halves so that the caller can put its own loads between them (everything the prologue needs
+// is then in flight together instead of one round trip after the other): ISSUE requests slots 0 .. 3; FINISH parks slots 0
+// and 1, requests 4 and 5, and leaves the fragments of slot 0 in frag[0] behind a barrier.
+#define TF_STREAM_ISSUE(wptr, wbytes)                                                            \
   do {                                                                                           \
     st.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wptr), 0, (int)(wbytes), 0x00020000); \
     st.next = threadIdx.x * 16u;                                                                 \
@@ -128,6 +152,9 @@ struct TfStream {
     TF_GLOAD(st, 1);                                                                             \
     TF_GLOAD(st, 2);                                                                             \
     TF_GLOAD(st, 3);                                                                             \
+  } while (0)
+#define TF_STREAM_FINISH()                                                                       \
+  do {                                                                                           \
     TF_PARK(st, 0, ring);                                                                        \
     TF_GLOAD(st, 0);                                                                             \
     TF_PARK(st, 1, ring + kTfSlot);                                                              \
@@ -190,6 +217,9 @@ struct TfLayerArgs {
   int tokens, ffn_tiles, nq;   // F / 16; channels of the next projection (<= 64)
   int w_bytes;
   float eps1, eps2;
+#ifdef SMOS_TF_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
@@ -200,7 +230,6 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   const int q = lane >> 4, n = lane & 15;
   const int F = a.ffn_tiles * 16;
   const int n_prm = 6 * kTfC + F + 64;
-  for (int i = threadIdx.x; i < n_prm; i += 256) prm[i] = a.params[i];
   const float* p_bo = prm;
   const float* p_g1 = prm + kTfC;
   const float* p_be1 = prm + 2 * kTfC;
@@ -210,6 +239,11 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   const float* p_be2 = p_g2 + kTfC;
   const float* p_bq = p_be2 + kTfC;
 
+  // prologue: the first weight slots, the two input tiles and the parameter block are requested together
+  TF_STAMP(0);
+  TfStream st;
+  float4 frag[2][8];
+  TF_STREAM_ISSUE(a.wstream, a.w_bytes);
   const int row = (int)blockIdx.x * 64 + wave * 16 + n;
   const bool live = row < a.tokens;
   const __amdgpu_buffer_rsrc_t ssrd =
@@ -218,16 +252,25 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.query), 0, (int)(a.tokens * a.q_pitch * 4), 0x00020000);
   const unsigned s_off = live ? (unsigned)(row * kTfC + 4 * q) * 4u : 0x80000000u;
   const unsigned q_off = live ? (unsigned)(row * (int)a.q_pitch + 4 * q) * 4u : 0x80000000u;
-
   tf4 xs[kTfT], xq[kTfT];                 // B tiles: sampled (then q1), query
 #pragma unroll
   for (int t = 0; t < kTfT; ++t) xs[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(ssrd, s_off + 64u * t, 0, 0));
 #pragma unroll
   for (int t = 0; t < kTfT; ++t) xq[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(qsrd, q_off + 64u * t, 0, 0));
-
-  TfStream st;
-  float4 frag[2][8];
-  TF_STREAM_BEGIN(a.wstream, a.w_bytes);           // its barrier also publishes prm
+  {
+    const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.params), 0, n_prm * 4, 0x00020000);
+    u32x4 pv[2];                          // n_prm <= 6 * 128 + 4096 + 64 floats: up to 5 float4 per thread; two rounds of up to 2048 floats
+    for (int base = 0; base < n_prm; base += 2048) {
+      pv[0] = __builtin_amdgcn_raw_buffer_load_b128(psrd, (unsigned)(base + 4 * (int)threadIdx.x) * 4u, 0, 0);
+      pv[1] = __builtin_amdgcn_raw_buffer_load_b128(psrd, (unsigned)(base + 1024 + 4 * (int)threadIdx.x) * 4u, 0, 0);
+      if (base + 4 * (int)threadIdx.x < n_prm) *reinterpret_cast<float4*>(prm + base + 4 * threadIdx.x) =
+          make_float4(__uint_as_float(pv[0].x), __uint_as_float(pv[0].y), __uint_as_float(pv[0].z), __uint_as_float(pv[0].w));
+      if (base + 1024 + 4 * (int)threadIdx.x < n_prm) *reinterpret_cast<float4*>(prm + base + 1024 + 4 * threadIdx.x) =
+          make_float4(__uint_as_float(pv[1].x), __uint_as_float(pv[1].y), __uint_as_float(pv[1].z), __uint_as_float(pv[1].w));
+    }
+  }
+  TF_STREAM_FINISH();                     // its barrier also publishes prm
+  TF_STAMP(1);
 
   // ---- output_proj: acc1[o] = sum_t P(o, t) xs[t] ----
   tf4 acc1[kTfT], ea, eb;
@@ -247,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
     TF_ROW_OUT(2, acc1[o_ + 2]);
     TF_ROW_OUT(3, acc1[o_ + 3]);
   }
+  TF_STAMP(2);
   // + bias + query -> LayerNorm 1 -> q1 (kept in xs: linear1's B operand and the second residual)
 #pragma unroll
   for (int t = 0; t < kTfT; ++t) {
@@ -274,6 +318,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
     hb[2] = fmaxf(hsum[2] + b_.z, 0.f);                                                 \
     hb[3] = fmaxf(hsum[3] + b_.w, 0.f);                                                 \
   } while (0)
+  TF_STAMP(3);
   TF_ROW_OUT(0, hsum);                           // linear1(0)
   TF_H_RELU(0);
 #pragma unroll 1
@@ -289,6 +334,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
   TF_SLOT_COL(2, TF_ACC_2, hb);                  // linear2(last - 1)
   TF_H_RELU(a.ffn_tiles - 1);
   TF_SLOT_COL(3, TF_ACC_2, hb);                  // linear2(last)
+  TF_STAMP(4);
 #undef TF_ACC_2
 #undef TF_H_RELU
   // + bias + q1 -> LayerNorm 2 -> the layer's output
@@ -308,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
     for (int t = 0; t < kTfT; ++t) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(xs[t]), osrd, o_off + 64u * t, 0, 0);
   }
 
+  TF_STAMP(5);
   // ---- the next layer's offset / logit projection on the fresh output (4 slots: up to 64 channels, nq stored) ----
   if (a.qp_next) {
     tf4 accq[4];
@@ -324,6 +371,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(v), nsrd, off, 0, 0);
     }
   }
+  TF_STAMP(6);
 #undef TF_B_T
 #undef TF_ROW_OUT
 }
@@ -362,7 +410,8 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
   for (int t = 0; t < kTfT; ++t) xs[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(xsrd, x_off + 64u * t, 0, 0));
   TfStream st;
   float4 frag[2][8];
-  TF_STREAM_BEGIN(jb.wstream, jb.tiles * kTfSlotBytes);
+  TF_STREAM_ISSUE(jb.wstream, jb.tiles * kTfSlotBytes);
+  TF_STREAM_FINISH();
   tf4 acc, ea, eb;
   const tf4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define TF_ACC_P(p) acc
@@ -451,6 +500,12 @@ extern "C" int smos_tfusion_layer(const float* sampled, const float* query, int6
   a.qp_next = qp_next; a.q_pitch = q_pitch; a.o_pitch = o_pitch; a.tokens = (int)tokens; a.ffn_tiles = (int)(ffn / 16);
   a.nq = (int)nq; a.eps1 = eps1; a.eps2 = eps2;
   a.w_bytes = (int)(smos_tfusion_layer_stream_floats(ffn, qp_next != nullptr) * 4);
+#ifdef SMOS_TF_STAMPS
+  {
+    const char* e = getenv("SMOS_TF_STAMP_PTR");
+    a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+  }
+#endif
   const size_t lds = (size_t)2 * kTfSlotBytes + (size_t)smos_tfusion_layer_param_floats(ffn) * sizeof(float);
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_layer), lds, 0, &ks, "tfusion_layer")) return rc;
