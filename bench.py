@@ -93,10 +93,8 @@ def algorithmic_bytes(label, ctx=None):
         tokens, c, ffn, nq = _tfusion_layer_dims(dims)
         return 4 * (3 * tokens * c + tokens * nq + c * c + 2 * c * ffn + c * nq)
     if name == "tfusion_project":
-        src, couts = dims.split("->")
-        tokens, c = (int(v) for v in src.split("x"))
-        couts = [int(v) for v in couts.split("+")]
-        return 4 * (len(couts) * tokens * c + tokens * sum(couts) + c * sum(couts))
+        jobs = _tfusion_jobs(dims)
+        return 4 * sum(t * c + t * o + c * o for t, c, o in jobs)
     if name == "conv_cl":
         # own implicit-GEMM conv (csrc/conv_igemm.hip): label B x Cin x H x W -> Cout x Ho x Wo k KHxKW [+res]
         geo = _conv_geometry(dims)
@@ -129,6 +127,16 @@ def _tfusion_layer_dims(dims):
     return tokens, c, ffn, int(q) if q else 0
 
 
+def _tfusion_jobs(dims):
+    """tfusion_project[T x 128 -> Cout, ...] -> [(tokens, cin, cout)]"""
+    jobs = []
+    for job in dims.split(","):
+        src, cout = job.split("->")
+        t, c = (int(v) for v in src.split("x"))
+        jobs.append((t, c, int(cout)))
+    return jobs
+
+
 def _conv_geometry(dims):
     src, rest = dims.split("->")
     dst, rest = rest.split("k", 1)
@@ -158,9 +166,7 @@ def algorithmic_flops(label, ctx=None):
         tokens, c, ffn, nq = _tfusion_layer_dims(dims)
         return 2 * tokens * (c * c + 2 * c * ffn + c * nq)
     if name == "tfusion_project":
-        src, couts = dims.split("->")
-        tokens, c = (int(v) for v in src.split("x"))
-        return 2 * tokens * c * sum(int(v) for v in couts.split("+"))
+        return 2 * sum(t * c * o for t, c, o in _tfusion_jobs(dims))
     if name == "stem_gemm":
         # sparse DownSample2D 192 -> 32 on the occupied cells: a cell of parity class c feeds STEM_TAPS[c] conv taps plus the
         # 1x1 pool branch (csrc/stem.hip).  Needs the frames' occupancy; without it the launch is priced by its bytes only.
@@ -210,6 +216,10 @@ def executed_launch_flops(label, wino=True, ctx=None, family=None):
     k x 3 / 3 x k one in the 1-D F(2, 3) form (conv_wino1d) two thirds of the direct count.  family = the kernel ops.py ran
     the label on (profiling.KernelTimer.family); without it the form is inferred from the label's shape as the engine would."""
     fl = algorithmic_flops(label, ctx)
+    live = (ctx or {}).get("live_fraction")
+    if live is not None and label.startswith(("point_head[", "pointnet_scatter[")):
+        # the runner leaves the scans' padding tails out (StreamRunner(skip_padding=True)): tiles of padding points are not computed
+        return int(fl * live)
     if family is not None:
         return fl * 4 // 9 if family == "conv_wino" else (fl * 2 // 3 if family == "conv_wino1d" else fl)
     if fl and wino and label.startswith("conv_cl["):
@@ -247,14 +257,14 @@ def dominant_family(table):
     return max(cand, key=lambda k: cand[k]["ms"]) if cand else None
 
 
-def executed_flops(engine, b, n, t, stem_class_rows):
+def executed_flops(engine, b, n, t, stem_class_rows, live_fraction=1.0):
     """FLOPs the engine really executes on the matrix cores for one scan (batch of b TTA samples, n padded points, t stacked
     scans): walks the engine's own folded weights.  Differs from the reference's dense count (0.53 TFLOP) by the
     sparse first stage (only occupied cells, only the taps their parity class feeds), by conv_1 running as a conv on the fine
     map + tap GEMMs of the coarse maps at their own resolution, and by the stride-1 3x3 layers running in the Winograd
     F(2x2, 3x3) form (4 instead of 9 multiply-adds per output and channel pair)."""
     hb, wb = engine.bev_hw
-    total = 2.0 * b * t * n * (8 * 64 + 64 * 64)                                # point MLP
+    total = 2.0 * b * t * n * (8 * 64 + 64 * 64) * live_fraction               # point MLP (padding-tail tiles are skipped)
     total += sum(2.0 * r * 192 * 32 * (taps + 1) for r, taps in zip(stem_class_rows, (1, 2, 2, 4)))   # sparse stem
 
     wino = getattr(engine, "wino", False)
@@ -305,7 +315,7 @@ def executed_flops(engine, b, n, t, stem_class_rows):
     k = engine.aux[2]
     total += 2.0 * b * k * (h0 * w0 * c0 + h1 * w1 * cc1 + h2 * w2 * cc2)
     heads = 2 if engine.refine is not None else 1
-    total += heads * 2.0 * b * n * (192 * 96 + 96 * 64 + 64 * k)
+    total += heads * 2.0 * b * n * (192 * 96 + 96 * 64 + 64 * k) * live_fraction
     return total
 
 
@@ -862,12 +872,14 @@ def main():
             stem_class_rows = tuple(float(np.mean([m[8 + c] - m[4 + c] for m in metas])) for c in range(4))
             ctx["stem_rows"] = float(np.mean([m[11] for m in metas]))
             ctx["stem_class_rows"] = stem_class_rows
+        if not args.no_skip_padding:
+            ctx["live_fraction"] = float(np.mean([d["n_valid"] for d, _ in dev_frames])) / FRAME_POINT_NUM
         roof, families = family_roofline(model, device, dev_frames, args, ctx, one_step)
         exec_tflop = None
         if eng is not None and eng.layout == "cl":
             d0 = dev_frames[0][0]
             bs, t, _, n = d0["pcds_xyzi"].shape[:4]
-            exec_tflop = executed_flops(eng, bs, n, t, stem_class_rows) / 1e12
+            exec_tflop = executed_flops(eng, bs, n, t, stem_class_rows, ctx.get("live_fraction", 1.0)) / 1e12
         line = {
             "metric": "LiDAR scans/sec (StreamMOS streaming inference + voxel voting)",
             "value": round(value, 3), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -897,6 +909,7 @@ def main():
             "second_half_ms_per_step": None if second_half_ms is None else round(second_half_ms, 3),
             "stem_rows_per_launch": None if ctx.get("stem_rows") is None else round(ctx["stem_rows"]),
             "stem_class_rows": [round(r) for r in stem_class_rows],
+            "live_fraction": None if ctx.get("live_fraction") is None else round(ctx["live_fraction"], 4),
             "kernel_families_serial": families,
             "hip_kernel_ms_per_step_warmup": {k: round(v[1] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }

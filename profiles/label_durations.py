@@ -33,6 +33,8 @@ if len(sys.argv) > 3:
             ctx["stem_rows"] = line["stem_rows_per_launch"]
         if line.get("stem_class_rows"):
             ctx["stem_class_rows"] = line["stem_class_rows"]
+        if line.get("live_fraction") is not None:
+            ctx["live_fraction"] = line["live_fraction"]
     except (OSError, ValueError, IndexError):
         pass
 step = kinds.steady_step(rows, key=lambda r: int(r["Start_Timestamp"]))

@@ -760,8 +760,8 @@ def tfusion_pack_linear(w):
     """w [cout, 128] -> the weight stream of one smos_tfusion_project job: cout zero-padded to a multiple of 64, slot o = the
     eight pairs (o, t = 0..7)."""
     cout, k = w.shape
-    if k != 128 or cout > 256:
-        raise RuntimeError("tfusion_pack_linear: expected [<=256, 128], got %s" % (tuple(w.shape),))
+    if k != 128 or cout > 2048:
+        raise RuntimeError("tfusion_pack_linear: expected [<=2048, 128], got %s" % (tuple(w.shape),))
     pad = (cout + 63) // 64 * 64
     wp = torch.zeros((pad, k), dtype=torch.float32, device=w.device)
     wp[:cout] = w
@@ -824,31 +824,33 @@ def _token_rows(name, t):
 
 
 def tfusion_project(jobs):
-    """jobs: up to four (x [..., 128] token rows, wstream = tfusion_pack_linear(W), bias [cout]) -> list of [tokens, cout]
-    outputs, ONE launch (csrc/tfusion.hip): the fusion's projections that depend on no previous layer."""
+    """jobs: up to four (x [..., 128] token rows, wstream = tfusion_pack_linear(W), bias [cout] -- or an int cout for a Linear
+    without bias) -> list of [tokens, cout] outputs, ONE launch (csrc/tfusion.hip): the fusion's projections that depend on no
+    previous layer; the decoder's tap products.  The jobs may have different token counts."""
     n = len(jobs)
     if not 1 <= n <= 4:
         raise RuntimeError("tfusion_project: 1..4 jobs")
-    xs, pit, ws, bs, outs, couts = ((ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(),
-                                    (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)())
+    xs, pit, ws, bs, outs, couts, toks = ((ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(),
+                                          (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)())
     res = []
-    tokens = None
     for j, (x, w, b) in enumerate(jobs):
-        _require_cuda("tfusion_project", x, w, b)
+        bias = None if isinstance(b, int) else b
+        _require_cuda("tfusion_project", x, w, bias)
         tk, pitch = _token_rows("tfusion_project", x)
-        if x.shape[-1] != 128 or (tokens is not None and tk != tokens):
-            raise RuntimeError("tfusion_project: every job reads the same number of 128-channel token rows")
-        tokens = tk
-        cout = int(b.shape[0])
+        if x.shape[-1] != 128:
+            raise RuntimeError("tfusion_project: 128-channel token rows expected")
+        cout = int(b) if bias is None else int(bias.shape[0])
         if w.numel() != (cout + 63) // 64 * 64 * 128:
             raise RuntimeError("tfusion_project: weight stream of %d floats for %d outputs" % (w.numel(), cout))
-        out = torch.empty((tokens, cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((tk, cout), dtype=torch.float32, device=x.device)
         res.append(out)
-        xs[j], pit[j], ws[j], bs[j], outs[j], couts[j] = x.data_ptr(), pitch, w.data_ptr(), b.data_ptr(), out.data_ptr(), cout
+        xs[j], pit[j], ws[j], outs[j], couts[j], toks[j] = x.data_ptr(), pitch, w.data_ptr(), out.data_ptr(), cout, tk
+        bs[j] = bias.data_ptr() if bias is not None else None
     lib = _lib.load()
     x0 = jobs[0][0]
-    with _on(x0.device), profiling.span("tfusion_project[%dx128->%s]" % (tokens, "+".join(str(int(c)) for c in couts))):
-        rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, couts, tokens, _stream(x0))
+    label = "tfusion_project[%s]" % ",".join("%dx128->%d" % (int(toks[j]), int(couts[j])) for j in range(n))
+    with _on(x0.device), profiling.span(label):
+        rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, couts, toks, _stream(x0))
     _lib.check(rc, "smos_tfusion_project")
     return res
 
@@ -889,6 +891,13 @@ class TapWeights:
         self.kn = self.nk.t().contiguous()                      # [Cin, 9*Cout]: the layout the library GEMM is fastest in
         self.zero = torch.zeros(9 * cout, dtype=torch.float32, device=w.device)
         self._conv = None
+        self._stream = None
+
+    def stream(self):
+        """the tap matrices in the operand order of smos_tfusion_project (Cin = 128)"""
+        if self._stream is None:
+            self._stream = tfusion_pack_linear(self.nk)
+        return self._stream
 
     def conv_operand(self):
         if self._conv is None:
@@ -903,7 +912,10 @@ def upconv_tap_weights(w, c0, c1):
 
 # The nine tap products: library GEMM by default; "conv" runs them on the own kernel as one 1x1 convolution with 9*C outputs
 # (measured in the step: 236.6 vs 238.8 scans/s -- K = 128 is only four stages per tile, so the epilogue dominates).
-_TAP_GEMM_OWN = os.environ.get("SMOS_TAP_GEMM", "mm") == "conv"
+# "tf" (default since round 4): the token-wise Linear kernel of the temporal fusion (csrc/tfusion.hip), both sources in one launch:
+# 0.26 -> 0.2x ms per step against the library GEMMs ("mm")
+_TAP_GEMM = os.environ.get("SMOS_TAP_GEMM", "tf")
+_TAP_GEMM_OWN = _TAP_GEMM == "conv"
 # x pass and y pass in one launch (smos_upconv_xy) where the geometry allows; "0": always the two launches (A/B, same results)
 _UPCONV_XY = os.environ.get("SMOS_UPCONV_XY", "1") != "0"
 
@@ -934,13 +946,23 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
         raise RuntimeError("upconv3x3: one or two upsampled sources, got %d" % len(sources))
     fused = _UPCONV_XY and all(lib.smos_upconv_xy_ok(src[0].shape[2], ho) for src in sources)
     zs, ts = [], []
+    pre = {}
+    if _TAP_GEMM == "tf":
+        # the tap products of every source that has none yet, as jobs of ONE launch of the token-wise Linear kernel
+        todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048]
+        if todo:
+            jobs = []
+            for i in todo:
+                x = sources[i][0]
+                jobs.append((x.permute(0, 2, 3, 1).reshape(-1, 128), sources[i][1].stream(), 9 * sources[i][1].cout))
+            pre = dict(zip(todo, tfusion_project(jobs)))
     with _on(conv_a.device):
-        for src in sources:
+        for i_src, src in enumerate(sources):
             x, wt = src[0], src[1]
             hs, ws, cin = x.shape[2], x.shape[3], x.shape[1]
             if wt.cin != cin or wt.cout != c:
                 raise RuntimeError("upconv3x3: tap weights are for %d -> %d channels, got %d -> %d" % (wt.cin, wt.cout, cin, c))
-            z = src[2] if len(src) > 2 and src[2] is not None else upconv_tap_products(x, wt)
+            z = src[2] if len(src) > 2 and src[2] is not None else (pre[i_src] if i_src in pre else upconv_tap_products(x, wt))
             if tuple(z.shape) != (b * hs * ws, 9 * c) or not z.is_contiguous():
                 raise RuntimeError("upconv3x3: tap products must be a contiguous [B*Hs*Ws, 9*C] matrix, got %s" % (tuple(z.shape),))
             zs.append((z, hs, ws))

@@ -1170,3 +1170,10 @@ def test_tfusion_project_against_float64(tokens):
         assert err <= 2e-6, err
     with pytest.raises(RuntimeError):
         ops.tfusion_project([(src.cpu(), ops.tfusion_pack_linear(ws[0][0]), ws[0][1])])
+    # jobs of different length, 1152 outputs without a bias: the decoder's tap products (csrc/upconv.hip) as jobs of one launch
+    short = torch.randn((max(tokens // 4, 1), 128), generator=gen).to(DEV)
+    wt = (torch.randn((1152, 128), generator=gen) / 128 ** 0.5).to(DEV)
+    a, b = ops.tfusion_project([(src, ops.tfusion_pack_linear(wt), 1152), (short, ops.tfusion_pack_linear(wt), 1152)])
+    for got, x in ((a, src), (b, short)):
+        want = F.linear(x.double(), wt.double())
+        assert got.shape == want.shape and (got.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
