@@ -445,85 +445,6 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
 #undef TF_EMIT
 }
 
-
-// The same with TWO token tiles per wave (128 tokens per block): every weight fragment read from LDS feeds eight MFMAs instead
-// of four and the weight stream passes through half as many blocks -- the form for long token lists (the decoder's tap
-// products: 65 536 + 16 384 tokens x 1 152 outputs), where one tile per wave would leave the LDS / L2 path twice as busy.
-__global__ __launch_bounds__(256, 1) void tfusion_project2(TfProjectArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float4* ring = reinterpret_cast<float4*>(lds);
-  const TfJob& jb = a.job[blockIdx.y];
-  if ((int)blockIdx.x * 128 >= jb.tokens) return;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, n = lane & 15;
-  const int row0 = (int)blockIdx.x * 128 + wave * 32 + n, row1 = row0 + 16;
-  const bool live0 = row0 < jb.tokens, live1 = row1 < jb.tokens;
-  const __amdgpu_buffer_rsrc_t xsrd =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.x), 0, (int)(jb.tokens * jb.xp * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(jb.out, 0, jb.tokens * jb.cout * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t bsrd =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.bias), 0, jb.bias ? jb.cout * 4 : 0, 0x00020000);
-  const unsigned x_off0 = live0 ? (unsigned)(row0 * (int)jb.xp + 4 * q) * 4u : 0x80000000u;
-  const unsigned x_off1 = live1 ? (unsigned)(row1 * (int)jb.xp + 4 * q) * 4u : 0x80000000u;
-  tf4 xa[kTfT], xb[kTfT];
-#pragma unroll
-  for (int t = 0; t < kTfT; ++t) xa[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(xsrd, x_off0 + 64u * t, 0, 0));
-#pragma unroll
-  for (int t = 0; t < kTfT; ++t) xb[t] = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(xsrd, x_off1 + 64u * t, 0, 0));
-  TfStream st;
-  float4 frag[2][8];
-  TF_STREAM_ISSUE(jb.wstream, jb.tiles * kTfSlotBytes);
-  TF_STREAM_FINISH();
-  tf4 ea0, eb0, ea1, eb1;
-  const tf4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#define TF_PAIR2(IDX, p_)                                                                        \
-  do {                                                                                           \
-    frag[((IDX) & 1) ^ 1][p_] = rd_[(p_) * 64];                                                  \
-    const float4 f_ = frag[(IDX) & 1][p_];                                                       \
-    ea0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.x, xa[p_][0], ea0, 0, 0, 0);                   \
-    ea1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.x, xb[p_][0], ea1, 0, 0, 0);                   \
-    eb0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.y, xa[p_][1], eb0, 0, 0, 0);                   \
-    eb1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.y, xb[p_][1], eb1, 0, 0, 0);                   \
-    ea0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.z, xa[p_][2], ea0, 0, 0, 0);                   \
-    ea1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.z, xb[p_][2], ea1, 0, 0, 0);                   \
-    eb0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.w, xa[p_][3], eb0, 0, 0, 0);                   \
-    eb1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f_.w, xb[p_][3], eb1, 0, 0, 0);                   \
-  } while (0)
-#define TF_EMIT2(o)                                                                                                    \
-  do {                                                                                                                 \
-    const tf4 b_ = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(bsrd, (unsigned)(16 * (o) + 4 * q) * 4u, 0, 0));       \
-    const bool in_ = 16 * (o) + 4 * q < jb.cout;                                                                       \
-    const unsigned o0_ = (live0 && in_) ? (unsigned)(row0 * jb.cout + 16 * (o) + 4 * q) * 4u : 0x80000000u;            \
-    const unsigned o1_ = (live1 && in_) ? (unsigned)(row1 * jb.cout + 16 * (o) + 4 * q) * 4u : 0x80000000u;            \
-    __builtin_amdgcn_raw_buffer_store_b128(as_u32x4((ea0 + eb0) + b_), osrd, o0_, 0, 0);                               \
-    __builtin_amdgcn_raw_buffer_store_b128(as_u32x4((ea1 + eb1) + b_), osrd, o1_, 0, 0);                               \
-  } while (0)
-#define TF_ROW_EMIT2(IDX, o)                                                                     \
-  do {                                                                                           \
-    ea0 = zero4; eb0 = zero4; ea1 = zero4; eb1 = zero4;                                          \
-    {                                                                                            \
-      TF_SLOT_HEAD(IDX);                                                                         \
-      TF_PAIR2(IDX, 0);                                                                          \
-      TF_PAIR2(IDX, 1);                                                                          \
-      SMOS_FENCE();                                                                              \
-      TF_SLOT_TAIL(IDX);                                                                         \
-      SMOS_FENCE();                                                                              \
-      _Pragma("unroll") for (int p_ = 2; p_ < 8; ++p_) TF_PAIR2(IDX, p_);                        \
-    }                                                                                            \
-    TF_EMIT2(o);                                                                                 \
-  } while (0)
-#pragma unroll 1
-  for (int o = 0; o < jb.tiles; o += 4) {
-    TF_ROW_EMIT2(0, o);
-    TF_ROW_EMIT2(1, o + 1);
-    TF_ROW_EMIT2(2, o + 2);
-    TF_ROW_EMIT2(3, o + 3);
-  }
-#undef TF_ROW_EMIT2
-#undef TF_EMIT2
-#undef TF_PAIR2
-}
-
 }  // namespace smos
 
 using namespace smos;
@@ -557,15 +478,6 @@ extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const
   const size_t lds = (size_t)2 * kTfSlotBytes;
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_project), lds, 0, &ks, "tfusion_project")) return rc;
-  // two token tiles per wave once that still leaves >= 2 blocks per CU (long token lists: the tap products)
-  int64_t blocks2 = 0;
-  for (int j = 0; j < n_jobs; ++j) blocks2 += (tokens[j] + 127) / 128;
-  if (blocks2 >= 2 * (int64_t)ks.cus) {
-    KernelSetup ks2;
-    if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_project2), lds, 0, &ks2, "tfusion_project")) return rc;
-    hipLaunchKernelGGL(tfusion_project2, dim3((unsigned)((most + 127) / 128), (unsigned)n_jobs), dim3(256), lds, (hipStream_t)stream, a);
-    return check_launch("tfusion_project");
-  }
   hipLaunchKernelGGL(tfusion_project, dim3((unsigned)((most + 63) / 64), (unsigned)n_jobs), dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("tfusion_project");
 }

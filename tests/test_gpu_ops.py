@@ -1177,22 +1177,3 @@ def test_tfusion_project_against_float64(tokens):
     for got, x in ((a, src), (b, short)):
         want = F.linear(x.double(), wt.double())
         assert got.shape == want.shape and (got.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
-
-
-def test_tfusion_project_two_tiles_per_wave_at_the_tap_product_shape():
-    """The decoder's tap products at the validation shape -- [4 x 128 x 128, 128] and [4 x 64 x 64, 128] rows x [128, 9 x 128] -- as
-    two jobs of one launch: long enough for the two-token-tiles-per-wave kernel (tfusion_project2; 640 blocks of 128 tokens).
-    Against float64, ragged last block included; and equal to the library GEMM form the engine used before (SMOS_TAP_GEMM=mm)."""
-    import torch.nn.functional as F
-    gen = torch.Generator(device="cpu").manual_seed(139)
-    a = torch.randn((65536 - 37, 128), generator=gen).to(DEV)
-    b = torch.randn((16384, 128), generator=gen).to(DEV)
-    w1 = (torch.randn((1152, 128), generator=gen) / 128 ** 0.5).to(DEV)
-    w2 = (torch.randn((1152, 128), generator=gen) / 128 ** 0.5).to(DEV)
-    za, zb = ops.tfusion_project([(a, ops.tfusion_pack_linear(w1), 1152), (b, ops.tfusion_pack_linear(w2), 1152)])
-    for got, x, w in ((za, a, w1), (zb, b, w2)):
-        want = F.linear(x.double(), w.double())
-        err = (got.double() - want).abs().max().item() / want.abs().max().item()
-        assert got.shape == want.shape and err <= 2e-6, err
-        lib = torch.addmm(torch.zeros(1152, device=DEV), x, w.t().contiguous())
-        assert (got - lib).abs().max().item() <= 4e-6 * want.abs().max().item()
