@@ -248,20 +248,21 @@ int smos_msda_fwd_qp(const float* value, const float* qp, float* out, int64_t N,
 
 /* Temporal fusion on the matrix cores (csrc/tfusion.hip; networks/multi_view_encoder.py:285-321 DeformAttnLayer,
  * deformattn/modules/ms_deform_attn.py:94-115 MSDeformAttn's projections).  d_model = 128.
- * smos_tfusion_project: up to four token-wise Linear jobs y = W x (+ b) in one launch -- the projections of a frame that depend
+ * smos_tfusion_project: up to eight token-wise Linear jobs y = W x (+ b) in one launch -- the projections of a frame that depend
  *   on no previous layer (value_proj of every layer, the first layer's [sampling_offsets | attention_weights]) and the
  *   decoder's tap products (the [B Hs Ws, 128] x [128, 9 * 128] GEMMs in front of smos_upconv_xy).  Host arrays of n_jobs
  *   entries; x[j] [tokens[j], *] rows of pitch x_pitch[j] floats (>= 128); wstream[j] = the weights as 16 x 16 blocks in MFMA
  *   operand order (streammos_amd.ops.tfusion_pack_linear: cout rounded up to a multiple of 64, zero padded); bias[j] [cout]
- *   or NULL; out[j] [tokens[j], cout] dense; cout a multiple of 4, <= 2048.
+ *   or NULL; out[j] [tokens[j], *] rows of pitch out_pitch[j] >= cout (a job may fill a column range of a wider matrix); cout a
+ *   multiple of 4, <= 2048.
  * smos_tfusion_layer: everything of one layer behind its sampler in one launch:
  *   q1 = norm1(query + output_proj(sampled)); out = norm2(q1 + linear2(relu(linear1(q1)))); and, if qp_next != NULL,
  *   qp_next = W_q out + b_q -- the NEXT layer's offset / logit projection (nq <= 64 channels), so that the following
  *   smos_msda_fwd_qp can start at once.  wstream / params = streammos_amd.ops.TfusionLayer (sizes:
  *   smos_tfusion_layer_stream_floats / _param_floats); ffn a multiple of 32. */
 int smos_tfusion_project(int32_t n_jobs, const float* const* x, const int64_t* x_pitch, const float* const* wstream,
-                         const float* const* bias, float* const* out, const int64_t* cout, const int64_t* tokens,
-                         smos_stream_t stream);
+                         const float* const* bias, float* const* out, const int64_t* out_pitch, const int64_t* cout,
+                         const int64_t* tokens, smos_stream_t stream);
 int64_t smos_tfusion_layer_param_floats(int64_t ffn);
 int64_t smos_tfusion_layer_stream_floats(int64_t ffn, int32_t has_next);
 int smos_tfusion_layer(const float* sampled, const float* query, int64_t q_pitch, const float* wstream, const float* params,

@@ -377,19 +377,19 @@ __global__ __launch_bounds__(256, 1) void tfusion_layer(TfLayerArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// tfusion_project: up to four independent token-wise Linear jobs (128 -> 16 * tiles) in one launch, blockIdx.y = job
+// tfusion_project: up to eight independent token-wise Linear jobs (128 -> 16 * tiles) in one launch, blockIdx.y = job
 // ------------------------------------------------------------------------------------------------------------------
 struct TfJob {
   const float* x;          // [tokens, *] pitch xp
   const float4* wstream;   // tiles slots (cout rounded up to a multiple of 64): slot o = P(o, t = 0..7)
   const float* bias;       // [cout]
-  float* out;              // [tokens, cout] dense rows
-  int64_t xp;
+  float* out;              // [tokens, *] rows of pitch op
+  int64_t xp, op;
   int cout, tiles;         // channels stored; slots streamed (a multiple of 4)
   int tokens;
 };
 struct TfProjectArgs {
-  TfJob job[4];
+  TfJob job[8];
 };
 
 __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
   const bool live = row < jb.tokens;
   const __amdgpu_buffer_rsrc_t xsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.x), 0, (int)(jb.tokens * jb.xp * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(jb.out, 0, jb.tokens * jb.cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(jb.out, 0, (int)(jb.tokens * jb.op * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t bsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.bias), 0, jb.bias ? jb.cout * 4 : 0, 0x00020000);
   const unsigned x_off = live ? (unsigned)(row * (int)jb.xp + 4 * q) * 4u : 0x80000000u;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
 #define TF_EMIT(o)                                                                                                     \
   do {                                                                                                                 \
     const tf4 b_ = as_tf4(__builtin_amdgcn_raw_buffer_load_b128(bsrd, (unsigned)(16 * (o) + 4 * q) * 4u, 0, 0));       \
-    const unsigned off_ = (live && 16 * (o) + 4 * q < jb.cout) ? (unsigned)(row * jb.cout + 16 * (o) + 4 * q) * 4u : 0x80000000u; \
+    const unsigned off_ = (live && 16 * (o) + 4 * q < jb.cout) ? (unsigned)(row * (int)jb.op + 16 * (o) + 4 * q) * 4u : 0x80000000u; \
     __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc + b_), osrd, off_, 0, 0);                                      \
   } while (0)
 #define TF_ROW_EMIT(IDX, o)             \
@@ -449,32 +449,34 @@ __global__ __launch_bounds__(256, 1) void tfusion_project(TfProjectArgs a) {
 
 using namespace smos;
 
-// Token-wise Linear layers y = W x (+ b) on 128-channel token rows, up to four jobs in one launch: the projections of a frame's
+// Token-wise Linear layers y = W x (+ b) on 128-channel token rows, up to eight jobs in one launch: the projections of a frame's
 // temporal fusion that do not depend on a previous layer (value_proj of every DeformAttnLayer and the first layer's
 // [sampling_offsets | attention_weights], deformattn/modules/ms_deform_attn.py:94-103), and the decoder's tap products
 // (csrc/upconv.hip: [B Hs Ws, 128] x [128, 9 * 128] for the two coarse maps).  Per job: x [tokens[j], *] (row pitch x_pitch
 // floats, >= 128), wstream = ops.tfusion_pack_linear(W) (cout rounded up to a multiple of 64, zero padded), bias [cout] or
-// NULL, out [tokens[j], cout] dense.  cout a multiple of 4, <= 2048; out < 2 GiB.
+// NULL, out [tokens[j], *] rows of pitch out_pitch[j] >= cout (a job may write a column range of a wider matrix).  cout a
+// multiple of 4, <= 2048; operands < 2 GiB.
 extern "C" int smos_tfusion_project(int32_t n_jobs, const float* const* x, const int64_t* x_pitch, const float* const* wstream,
-                                    const float* const* bias, float* const* out, const int64_t* cout, const int64_t* tokens,
-                                    smos_stream_t stream) {
-  SMOS_REQUIRE(n_jobs >= 1 && n_jobs <= 4 && x && x_pitch && wstream && bias && out && cout && tokens, "tfusion_project: 1..4 jobs");
+                                    const float* const* bias, float* const* out, const int64_t* out_pitch, const int64_t* cout,
+                                    const int64_t* tokens, smos_stream_t stream) {
+  SMOS_REQUIRE(n_jobs >= 1 && n_jobs <= 8 && x && x_pitch && wstream && bias && out && out_pitch && cout && tokens,
+               "tfusion_project: 1..8 jobs");
   TfProjectArgs a;
   int64_t most = 0;
   for (int j = 0; j < n_jobs; ++j) {
     SMOS_REQUIRE(x[j] && wstream[j] && out[j] && x_pitch[j] >= kTfC && x_pitch[j] % 4 == 0 && cout[j] > 0 && cout[j] % 4 == 0 &&
-                     cout[j] <= 2048 && tokens[j] > 0 && tokens[j] < (1LL << 22),
-                 "tfusion_project: bad job (pitch >= 128, cout a multiple of 4 and <= 2048, 0 < tokens < 2^22)");
+                     cout[j] <= 2048 && out_pitch[j] >= cout[j] && out_pitch[j] % 4 == 0 && tokens[j] > 0 && tokens[j] < (1LL << 22),
+                 "tfusion_project: bad job (pitch >= 128, cout a multiple of 4 and <= 2048, out pitch >= cout, 0 < tokens < 2^22)");
     SMOS_REQUIRE(((reinterpret_cast<uintptr_t>(x[j]) | reinterpret_cast<uintptr_t>(wstream[j]) | reinterpret_cast<uintptr_t>(bias[j]) |
                    reinterpret_cast<uintptr_t>(out[j])) & 15) == 0, "tfusion_project: pointers must be 16-byte aligned");
-    SMOS_REQUIRE(tokens[j] * x_pitch[j] * 4 < (1LL << 31) && tokens[j] * cout[j] * 4 < (1LL << 31),
+    SMOS_REQUIRE(tokens[j] * x_pitch[j] * 4 < (1LL << 31) && tokens[j] * out_pitch[j] * 4 < (1LL << 31),
                  "tfusion_project: an operand larger than 2 GiB");
     a.job[j].x = x[j]; a.job[j].wstream = reinterpret_cast<const float4*>(wstream[j]); a.job[j].bias = bias[j]; a.job[j].out = out[j];
-    a.job[j].xp = x_pitch[j]; a.job[j].cout = (int)cout[j]; a.job[j].tiles = (int)((cout[j] + 63) / 64 * 4);
+    a.job[j].xp = x_pitch[j]; a.job[j].op = out_pitch[j]; a.job[j].cout = (int)cout[j]; a.job[j].tiles = (int)((cout[j] + 63) / 64 * 4);
     a.job[j].tokens = (int)tokens[j];
     most = tokens[j] > most ? tokens[j] : most;
   }
-  for (int j = n_jobs; j < 4; ++j) a.job[j] = a.job[0];
+  for (int j = n_jobs; j < 8; ++j) a.job[j] = a.job[0];
   const size_t lds = (size_t)2 * kTfSlotBytes;
   KernelSetup ks;
   if (int rc = kernel_setup(reinterpret_cast<const void*>(&tfusion_project), lds, 0, &ks, "tfusion_project")) return rc;

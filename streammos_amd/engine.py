@@ -330,8 +330,8 @@ class InferenceEngine:
             query = query if query.is_contiguous() else query.contiguous()
             jobs = [(src, L.wv_stream, L.value[1]) for L in self.layers] + [(query, self.layers[0].wq_stream, self.layers[0].qproj[1])]
             outs = []
-            for k in range(0, len(jobs), 4):
-                outs += ops.tfusion_project(jobs[k:k + 4])
+            for k in range(0, len(jobs), 8):
+                outs += ops.tfusion_project(jobs[k:k + 8])
             qp = outs[-1]
             for i, L in enumerate(self.layers):
                 sampled = ops.msda_fwd_qp(outs[i].view(b, lq, L.heads, 32), qp.view(b, lq, -1), hh, ww, L.points)

@@ -824,16 +824,18 @@ def _token_rows(name, t):
 
 
 def tfusion_project(jobs):
-    """jobs: up to four (x [..., 128] token rows, wstream = tfusion_pack_linear(W), bias [cout] -- or an int cout for a Linear
-    without bias) -> list of [tokens, cout] outputs, ONE launch (csrc/tfusion.hip): the fusion's projections that depend on no
-    previous layer; the decoder's tap products.  The jobs may have different token counts."""
+    """jobs: up to eight (x [..., 128] token rows, wstream = tfusion_pack_linear(W), bias [cout] -- or an int cout for a Linear
+    without bias[, out: a [tokens, cout] view with contiguous channels, e.g. a column range of a wider matrix]) -> list of
+    [tokens, cout] outputs, ONE launch (csrc/tfusion.hip): the fusion's projections that depend on no previous layer; the
+    decoder's tap products.  The jobs may have different token counts."""
     n = len(jobs)
-    if not 1 <= n <= 4:
-        raise RuntimeError("tfusion_project: 1..4 jobs")
-    xs, pit, ws, bs, outs, couts, toks = ((ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(),
-                                          (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)())
+    if not 1 <= n <= 8:
+        raise RuntimeError("tfusion_project: 1..8 jobs")
+    xs, pit, ws, bs, outs, ops_, couts, toks = ((ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(),
+                                                (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)())
     res = []
-    for j, (x, w, b) in enumerate(jobs):
+    for j, job in enumerate(jobs):
+        x, w, b = job[0], job[1], job[2]
         bias = None if isinstance(b, int) else b
         _require_cuda("tfusion_project", x, w, bias)
         tk, pitch = _token_rows("tfusion_project", x)
@@ -842,15 +844,21 @@ def tfusion_project(jobs):
         cout = int(b) if bias is None else int(bias.shape[0])
         if w.numel() != (cout + 63) // 64 * 64 * 128:
             raise RuntimeError("tfusion_project: weight stream of %d floats for %d outputs" % (w.numel(), cout))
-        out = torch.empty((tk, cout), dtype=torch.float32, device=x.device)
+        if len(job) > 3 and job[3] is not None:
+            out = job[3]
+            _require_cuda("tfusion_project", out)
+            if out.dim() != 2 or tuple(out.shape) != (tk, cout) or out.stride(1) != 1 or out.dtype != torch.float32:
+                raise RuntimeError("tfusion_project: out must be a float32 [tokens, cout] view with contiguous channels")
+        else:
+            out = torch.empty((tk, cout), dtype=torch.float32, device=x.device)
         res.append(out)
-        xs[j], pit[j], ws[j], outs[j], couts[j], toks[j] = x.data_ptr(), pitch, w.data_ptr(), out.data_ptr(), cout, tk
+        xs[j], pit[j], ws[j], outs[j], ops_[j], couts[j], toks[j] = x.data_ptr(), pitch, w.data_ptr(), out.data_ptr(), out.stride(0), cout, tk
         bs[j] = bias.data_ptr() if bias is not None else None
     lib = _lib.load()
     x0 = jobs[0][0]
     label = "tfusion_project[%s]" % ",".join("%dx128->%d" % (int(toks[j]), int(couts[j])) for j in range(n))
     with _on(x0.device), profiling.span(label):
-        rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, couts, toks, _stream(x0))
+        rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, ops_, couts, toks, _stream(x0))
     _lib.check(rc, "smos_tfusion_project")
     return res
 
@@ -893,11 +901,14 @@ class TapWeights:
         self._conv = None
         self._stream = None
 
-    def stream(self):
-        """the tap matrices in the operand order of smos_tfusion_project (Cin = 128)"""
+    def stream(self, parts=1):
+        """the tap matrices in the operand order of smos_tfusion_project (Cin = 128), cut into `parts` equal output ranges"""
         if self._stream is None:
-            self._stream = tfusion_pack_linear(self.nk)
-        return self._stream
+            self._stream = {}
+        if parts not in self._stream:
+            n = self.nk.shape[0] // parts
+            self._stream[parts] = [tfusion_pack_linear(self.nk[i * n:(i + 1) * n]) for i in range(parts)]
+        return self._stream[parts]
 
     def conv_operand(self):
         if self._conv is None:
@@ -916,6 +927,7 @@ def upconv_tap_weights(w, c0, c1):
 # 0.26 -> 0.2x ms per step against the library GEMMs ("mm")
 _TAP_GEMM = os.environ.get("SMOS_TAP_GEMM", "tf")
 _TAP_GEMM_OWN = _TAP_GEMM == "conv"
+_TAP_PARTS = int(os.environ.get("SMOS_TAP_PARTS", "3"))      # column ranges per source in the tap-product launch (tuning knob)
 # x pass and y pass in one launch (smos_upconv_xy) where the geometry allows; "0": always the two launches (A/B, same results)
 _UPCONV_XY = os.environ.get("SMOS_UPCONV_XY", "1") != "0"
 
@@ -951,11 +963,19 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
         # the tap products of every source that has none yet, as jobs of ONE launch of the token-wise Linear kernel
         todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048]
         if todo:
+            # every source's outputs in `parts` column ranges = parts x len(todo) jobs of 64-token blocks:
+            # column ranges shorten the last, partly empty round of resident blocks (tools/ubench_taps.py: 0.230 / 0.213 / 0.211 ms for 1 / 2 / 3 ranges; library GEMMs 0.278)
+            parts = _TAP_PARTS if len(todo) * _TAP_PARTS <= 8 and (9 * sources[todo[0]][1].cout) % (64 * _TAP_PARTS) == 0 else 1
             jobs = []
             for i in todo:
-                x = sources[i][0]
-                jobs.append((x.permute(0, 2, 3, 1).reshape(-1, 128), sources[i][1].stream(), 9 * sources[i][1].cout))
-            pre = dict(zip(todo, tfusion_project(jobs)))
+                x, wt = sources[i][0], sources[i][1]
+                rows = x.permute(0, 2, 3, 1).reshape(-1, 128)
+                z = torch.empty((rows.shape[0], 9 * wt.cout), dtype=torch.float32, device=x.device)
+                pre[i] = z
+                n = 9 * wt.cout // parts
+                for k, ws_k in enumerate(wt.stream(parts)):
+                    jobs.append((rows, ws_k, n, z[:, k * n:(k + 1) * n]))
+            tfusion_project(jobs)
     with _on(conv_a.device):
         for i_src, src in enumerate(sources):
             x, wt = src[0], src[1]
