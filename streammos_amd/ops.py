@@ -961,7 +961,9 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
     pre = {}
     if _TAP_GEMM == "tf":
         # the tap products of every source that has none yet, as jobs of ONE launch of the token-wise Linear kernel
-        todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048]
+        # (a product matrix of 2 GiB and more -- 16 concurrent streams -- stays on the library GEMM: 32-bit buffer offsets)
+        todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048 and
+                src[0].shape[0] * src[0].shape[2] * src[0].shape[3] * 9 * src[1].cout * 4 < (1 << 31)]
         if todo:
             # every source's outputs in `parts` column ranges = parts x len(todo) jobs of 64-token blocks:
             # column ranges shorten the last, partly empty round of resident blocks (tools/ubench_taps.py: 0.230 / 0.213 / 0.211 ms for 1 / 2 / 3 ranges; library GEMMs 0.278)
