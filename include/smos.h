@@ -447,6 +447,14 @@ int smos_channel_gate_apply_cl(const float* y, int64_t y_pitch, const float* bia
 int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
                             const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
                             smos_stream_t stream);
+/* DownSample2D's tail with the pool branch computed on the fly (networks/backbone.py:105-134; csrc/downsample.hip):
+ * out = relu(a + bias + maxpool3x3(conv1x1(x, w); stride, pad 1)) -- replaces smos_conv_cl (1x1, full resolution) +
+ * smos_downsample_epilogue_cl; q = W x stays in LDS.  x [B,H,W,*] pitch x_pitch; wpairs = the [Cout, Cin] weights (BN folded) as
+ * 16 x 16 blocks in MFMA operand order (streammos_amd.ops.pool_branch_prepare); a / out [B,Ho,Wo,*]; Cin == Cout in {32, 64, 128}
+ * (128 at stride 2 only); stride 1 or 2. */
+int smos_downsample_pool_branch(const float* x, int64_t x_pitch, const float* wpairs, const float* a, int64_t a_pitch,
+                                const float* bias, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                                int64_t Cout, int32_t stride, smos_stream_t stream);
 /* smos_gather_scatter with a channels-last source grid [B,Hg,Wg,*] and target [B,Ho,Wo,*]; C is 32 or 64. */
 int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
                            const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch, float* pts_out,

@@ -74,6 +74,7 @@ SIGNATURES = {
     "smos_channel_gate_apply_cl": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, vp],
     "smos_upsample_concat_cl": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
     "smos_gather_scatter_cl": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
+    "smos_downsample_pool_branch": [vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
     "smos_gather_scatter_cl_live": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }

@@ -450,6 +450,14 @@ class InferenceEngine:
     def _block_cl(self, x, p, out=None):
         if p.kind == "down":
             a = self._conv(x, p.wa, None, NONE, stride=p.stride)
+            cout, cin = p.wp.shape[0], p.wp.shape[1]
+            if self.pool_fused and self.own_conv and ops.pool_branch_ok(cin, cout, p.stride) and x.shape[0] * x.shape[2] * x.shape[3] * x.stride(3) * 4 < (1 << 31):
+                # the 1x1 pool-branch conv, the 3x3 max pool and the tail in one launch (csrc/downsample.hip): the full-resolution
+                # branch map is never written
+                wq = p.__dict__.get("wq")
+                if wq is None:
+                    wq = p.__dict__["wq"] = ops.pool_branch_prepare(p.wp)
+                return ops.downsample_pool_branch(x, wq, a, p.bias, p.stride, out=out if out is not None else a)
             q = self._conv(x, p.wp, None, NONE)
             return ops.downsample_epilogue_cl(a, q, p.bias, p.stride, out=out if out is not None else a)
         if p.kind == "unbalance":

@@ -1359,6 +1359,40 @@ def downsample_epilogue_cl(a, p, bias, stride, out=None):
     return out
 
 
+def pool_branch_prepare(w):
+    """1x1 pool-branch weights [Cout, Cin(, 1, 1)] (BatchNorm folded) -> the operand block of smos_downsample_pool_branch."""
+    w2 = w.reshape(w.shape[0], -1)
+    if w2.shape[0] != w2.shape[1] or w2.shape[0] not in (32, 64, 128):
+        raise RuntimeError("pool_branch_prepare: Cin == Cout in {32, 64, 128} expected, got %s" % (tuple(w.shape),))
+    return _tf_pairs(w2).reshape(-1).contiguous()
+
+
+def pool_branch_ok(cin, cout, stride):
+    """Shapes smos_downsample_pool_branch covers."""
+    return cin == cout and cin in (32, 64, 128) and stride in (1, 2) and not (cin == 128 and stride == 1)
+
+
+def downsample_pool_branch(x, wpairs, a, bias, stride, out=None):
+    """relu(a + bias + maxpool3x3(conv1x1(x); stride, pad 1)) on channels-last views in one launch (csrc/downsample.hip): the
+    DownSample2D tail with its pool branch computed on the fly; wpairs = pool_branch_prepare(w)."""
+    _require_cuda("downsample_pool_branch", x, wpairs, a, bias, out)
+    b, c, h, w = x.shape
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    if tuple(a.shape) != (b, c, ho, wo) or wpairs.numel() != c * c or not pool_branch_ok(c, c, stride):
+        raise RuntimeError("downsample_pool_branch: unsupported shapes x %s a %s stride %d" % (tuple(x.shape), tuple(a.shape), stride))
+    if out is None:
+        out = empty_cl(b, c, ho, wo, x.device)
+    elif tuple(out.shape) != (b, c, ho, wo):
+        raise RuntimeError("downsample_pool_branch: out has shape %s" % (tuple(out.shape),))
+    lib = _lib.load()
+    with _on(x.device), profiling.span("downsample_pool_branch[%dx%dx%dx%d/s%d]" % (b, c, h, w, stride)):
+        rc = lib.smos_downsample_pool_branch(x.data_ptr(), _cl("downsample_pool_branch", x), wpairs.data_ptr(), a.data_ptr(),
+                                             _cl("downsample_pool_branch", a), bias.data_ptr(), out.data_ptr(),
+                                             _cl("downsample_pool_branch", out), b, h, w, c, c, int(stride), _stream(x))
+    _lib.check(rc, "smos_downsample_pool_branch")
+    return out
+
+
 def channel_gate_residual_cl(y, bias, w1, b1, w2, b2, xres, ws, out=None):
     _require_cuda("channel_gate_residual_cl", y, bias, w1, b1, w2, b2, xres, ws, out)
     b, c, h, w = y.shape

@@ -135,19 +135,22 @@ def test_fused_engine_equals_module_graph(model):
 def test_engine_variants_agree(model):
     """The engine's A/B switches select other kernels for the same function: row-staging convolution on / off / also at 64
     outputs per block, ChannelAtt pool sums from the conv epilogue or from their own pass, the temporal fusion on the own
-    MFMA kernels (csrc/tfusion.hip) or as library GEMMs + add_layer_norm.  Same fp32 products, other
+    MFMA kernels (csrc/tfusion.hip) or as library GEMMs + add_layer_norm, the DownSample2D pool branch fused (csrc/downsample.hip)
+    or as 1x1 conv + epilogue pass.  Same fp32 products, other
     summation orders: 1e-5 of the range; every variant leaves the default flags behind."""
     frames = list(cases.e2e_frames(2))
     model.fast_inference, model.engine_layout = True, "cl"
     with torch.no_grad():
         eng = model._engine_for(torch.zeros(1, device=DEV))
     assert eng is not None and eng.layout == "cl"
-    default = (eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion)
+    assert eng.pool_fused
+    default = (eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion, eng.pool_fused)
     assert eng.tfusion and eng._tf_ok                     # the fused temporal-fusion kernels are what runs by default
     outs = []
     try:
-        for rows, rows_mt, sums, tfu in (default, (0, 1, True, True), (3, 2, True, True), (3, 1, False, True), default[:3] + (False,)):
-            eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion = rows, rows_mt, sums, tfu
+        for variant in (default, (0, 1, True, True, True), (3, 2, True, True, True), (3, 1, False, True, True),
+                        default[:3] + (False, True), default[:4] + (False,)):
+            eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion, eng.pool_fused = variant
             memory, res = None, []
             with torch.no_grad():
                 for i, batch in enumerate(frames):
@@ -156,7 +159,7 @@ def test_engine_variants_agree(model):
                     res.append((pred.clone(), memory.clone()))
             outs.append(res)
     finally:
-        eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion = default
+        eng.conv_rows, eng.conv_rows_mt, eng.fused_gate_sums, eng.tfusion, eng.pool_fused = default
     for other in outs[1:]:
         for (p0, m0), (p1, m1) in zip(outs[0], other):
             assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()

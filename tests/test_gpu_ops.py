@@ -1177,3 +1177,37 @@ def test_tfusion_project_against_float64(tokens):
     for got, x in ((a, src), (b, short)):
         want = F.linear(x.double(), wt.double())
         assert got.shape == want.shape and (got.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("c,hw,stride,b", [(64, (256, 256), 2, 4), (128, (128, 128), 2, 4), (32, (32, 1024), 1, 4), (64, (16, 512), 1, 4),
+                                           (64, (41, 71), 2, 2), (128, (9, 37), 2, 3), (32, (13, 45), 1, 2), (64, (5, 3), 1, 1),
+                                           (32, (6, 100), 2, 2), (64, (1, 1), 2, 1)])
+def test_downsample_pool_branch_against_float64_and_the_two_launch_form(c, hw, stride, b):
+    """csrc/downsample.hip: relu(a + bias + maxpool3x3(conv1x1(x); stride, pad 1)) -- the DownSample2D tail with its pool branch
+    computed on the fly (networks/backbone.py:105-134) -- at the network's four shapes and on ragged ones (tiles cut by every
+    border, maps smaller than a tile, all-negative windows at the border: a tap outside the image must not count as 0), inputs
+    and output as channel slices, output written over `a` as the engine does; against float64 and against the two launches it
+    replaces (smos_conv_cl 1x1 + smos_downsample_epilogue_cl)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(149)
+    h, w = hw
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    xw = (torch.randn((b, h, w, c + 32), generator=gen) - 0.5).to(DEV)          # mostly negative pool inputs near the borders too
+    x = xw[..., 16:16 + c].permute(0, 3, 1, 2)
+    wt = (torch.randn((c, c, 1, 1), generator=gen) / c ** 0.5).to(DEV)
+    aw = torch.randn((b, ho, wo, c + 8), generator=gen).to(DEV)
+    a = aw[..., :c].permute(0, 3, 1, 2)
+    bias = (torch.randn(c, generator=gen) - 1.0).to(DEV)
+    want = F.relu(a.double() + bias.double()[None, :, None, None] + F.max_pool2d(F.conv2d(x.double(), wt.double()), 3, stride, 1))
+    got = ops.downsample_pool_branch(x, ops.pool_branch_prepare(wt), a, bias, stride)
+    err = (got.double() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+    print("pool branch %d ch @%s /%d: %.2e of range" % (c, hw, stride, err))
+    assert got.shape == want.shape and err <= 2e-6, err
+    if c % 32 == 0:
+        qf = ops.conv_cl(x, ops.conv_prepare(wt, 1), None, 0, c, (1, 1), mt=1)
+        two = ops.downsample_epilogue_cl(a.clone(memory_format=torch.preserve_format), qf, bias, stride)
+        assert (got - two).abs().max().item() <= 4e-6 * max(want.abs().max().item(), 1e-6)
+    # in place over `a` (engine._block_cl), neighbours of the slice untouched
+    keep = aw[..., c:].clone()
+    inplace = ops.downsample_pool_branch(x, ops.pool_branch_prepare(wt), a, bias, stride, out=a)
+    assert torch.equal(inplace, got) and torch.equal(aw[..., c:], keep)
