@@ -171,6 +171,7 @@ class InferenceEngine:
         self.fused_gate_sums = os.environ.get("SMOS_GATE_SUMS", "1") != "0"      # ChannelAtt pool sums from the conv epilogue
         self.wino = os.environ.get("SMOS_WINO", "1") != "0"      # Winograd F(2x2,3x3) for the stride-1 3x3 layers (A/B switch)
         self.wino1d = os.environ.get("SMOS_WINO1D", "1") != "0"  # 1-D Winograd F(2,3) for the k x 3 / 3 x k layers (A/B switch)
+        self.pool_fused = os.environ.get("SMOS_POOL_FUSED", "1") != "0"   # DownSample2D pool branch + tail in one launch (A/B switch)
         self._wprep = {}
         self._shapes = None
         self._lsi = None
