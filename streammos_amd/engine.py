@@ -452,9 +452,13 @@ class InferenceEngine:
         if p.kind == "down":
             a = self._conv(x, p.wa, None, NONE, stride=p.stride)
             cout, cin = p.wp.shape[0], p.wp.shape[1]
-            if self.pool_fused and self.own_conv and ops.pool_branch_ok(cin, cout, p.stride) and x.shape[0] * x.shape[2] * x.shape[3] * x.stride(3) * 4 < (1 << 31):
+            if (self.pool_fused and self.own_conv and cin <= 64 and ops.pool_branch_ok(cin, cout, p.stride) and
+                    x.shape[0] * x.shape[2] * x.shape[3] * x.stride(3) * 4 < (1 << 31)):
                 # the 1x1 pool-branch conv, the 3x3 max pool and the tail in one launch (csrc/downsample.hip): the full-resolution
-                # branch map is never written
+                # branch map is never written.  Measured (tools/ubench_pool.py): 64 ch @256^2 /2 0.044 vs 0.047 ms for the two
+                # launches, 32 ch @32x1024 /1 0.019 vs 0.023, 64 ch @16x512 /1 0.014 vs 0.020 -- and 128 ch @128^2 /2 0.043 vs
+                # 0.037: the 1x1 conv is not as HBM-bound as it looks (2.1 GFLOP x 1.29 halo recompute = 19 us at the matrix
+                # peak), so the 128-channel block keeps the two launches
                 wq = p.__dict__.get("wq")
                 if wq is None:
                     wq = p.__dict__["wq"] = ops.pool_branch_prepare(p.wp)
