@@ -88,6 +88,12 @@ def algorithmic_bytes(label, ctx=None):
         b, ho, wo, c = (int(v) for v in dst.split("x"))
         cells = sum(int(hw.split("x")[0]) * int(hw.split("x")[1]) for hw in srcs.split("+"))
         return 4 * (2 * b * ho * wo * c + b * cells * 9 * c)
+    if name == "downsample_pool_branch":
+        # x in (once), the conv-branch result a in, the block's output out: the 1x1 branch map never leaves the CU (csrc/downsample.hip)
+        geo, stride = dims.split("/s")
+        b, c, h, w = (int(v) for v in geo.split("x"))
+        s_ = int(stride)
+        return 4 * (b * c * h * w + 2 * b * c * ((h - 1) // s_ + 1) * ((w - 1) // s_ + 1) + c * c)
     if name == "tfusion_layer":
         # sampled + query in, the layer's output (and the next layer's projection) out, the weight stream once (csrc/tfusion.hip)
         tokens, c, ffn, nq = _tfusion_layer_dims(dims)
@@ -162,6 +168,10 @@ def algorithmic_flops(label, ctx=None):
     if name == "conv_cl":
         geo = _conv_geometry(dims)
         return 2 * geo["b"] * geo["ho"] * geo["wo"] * geo["cout"] * geo["cin"] * geo["kh"] * geo["kw"]
+    if name == "downsample_pool_branch":
+        geo, _ = dims.split("/s")
+        b, c, h, w = (int(v) for v in geo.split("x"))
+        return 2 * b * h * w * c * c                    # the 1x1 conv at full resolution (the halo recompute is not algorithmic)
     if name == "tfusion_layer":
         tokens, c, ffn, nq = _tfusion_layer_dims(dims)
         return 2 * tokens * (c * c + 2 * c * ffn + c * nq)

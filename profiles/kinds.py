@@ -11,6 +11,7 @@ KIND = (
     (("upconv_ypass", "upconv_fused"), "upconv_ypass[", 1),
     (("upconv_xy",), "upconv_xy[", 1),
     (("msda_fwd",), "msda_fwd[", 1),
+    (("pool_branch",), "downsample_pool_branch[", 1),
     (("tfusion_layer",), "tfusion_layer[", 1),
     (("tfusion_project",), "tfusion_project[", 1),
     (("stem_mark", "stem_scan"), "stem_mark+scan[", 2),
