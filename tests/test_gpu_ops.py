@@ -1211,3 +1211,34 @@ def test_downsample_pool_branch_against_float64_and_the_two_launch_form(c, hw, s
     keep = aw[..., c:].clone()
     inplace = ops.downsample_pool_branch(x, ops.pool_branch_prepare(wt), a, bias, stride, out=a)
     assert torch.equal(inplace, got) and torch.equal(aw[..., c:], keep)
+
+
+@pytest.mark.parametrize("n_live", [0, 1, 31, 32, 1000, 2047, 2048, 5000])
+def test_point_head_and_gathers_leave_the_padding_tail_out(n_live):
+    """The `_live` entry points (smos_point_head_live, smos_gather_scatter_cl_live; include/smos.h): given a DEVICE-side count of
+    the real points at the front of every sample they produce the same values for those points, bit for bit, and zeros / nothing
+    for the tail [n_live, N) -- for counts of 0, inside a tile, at tile borders, N and beyond N (clamped)."""
+    gen = torch.Generator(device="cpu").manual_seed(151)
+    b, n = 3, 2048
+    rows = torch.randn((b, n, 192), generator=gen).to(DEV)
+    l1 = ((torch.randn((96, 192, 1, 1), generator=gen) * 0.1).to(DEV), (torch.randn(96, generator=gen) * 0.2).to(DEV))
+    l2 = ((torch.randn((64, 96, 1, 1), generator=gen) * 0.15).to(DEV), (torch.randn(64, generator=gen) * 0.2).to(DEV))
+    l3 = ((torch.randn((3, 64, 1, 1), generator=gen) * 0.2).to(DEV), torch.randn(3, generator=gen).to(DEV))
+    wprep, m3 = ops.point_head_prepare(l1, l2, l3)
+    full = ops.point_head(rows, wprep, m3)
+    cnt = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    live = ops.point_head(rows, wprep, m3, n_live=cnt)
+    k = min(n_live, n)
+    assert torch.equal(live[:, :, :k], full[:, :, :k]) and float(live[:, :, k:].abs().sum()) == 0.0
+    # the gather of point rows: real points identical; tail rows that lie outside the source map stay untouched
+    c, hw = 64, (32, 64)
+    grid = _to_cl(torch.relu(torch.randn((b, c) + hw, generator=gen)).to(DEV))
+    coord = _model_like_coords(gen, b, n, hw[0] / 0.5, hw[1] / 0.5).to(DEV)
+    coord[:, k:] = -4864.0                                        # what the reference's padding looks like after quantisation
+    want = torch.full((b, n, c), 3.0, device=DEV)
+    ops.gather_scatter_cl(grid, coord, (0.5, 0.5), pts_out=want)
+    got = torch.full((b, n, c), 3.0, device=DEV)
+    ops.gather_scatter_cl(grid, coord, (0.5, 0.5), pts_out=got, n_live=cnt)
+    assert torch.equal(got[:, :k], want[:, :k])
+    tail = got[:, (k + 63) // 64 * 64:]                           # whole 64-point runs inside the tail are skipped
+    assert tail.numel() == 0 or bool((tail == 3.0).all())
