@@ -405,7 +405,11 @@ class InferenceEngine:
         on channels-last maps: one launch of csrc/conv_igemm.hip; the operand-ordered copy of w is made once per (weight,
         mt).  With SMOS_OWN_CONV=0: MIOpen conv + the separate bias / activation / residual pass."""
         cout, cin, kh, kw = w.shape
-        if not self.own_conv or not ops.conv_cl_supported(x, cout, (kh, kw), stride, residual, out):
+        # fast accept (no per-launch predicate walk): channel counts the MFMA tiling covers and operands far below the 2 GiB of the
+        # 32-bit buffer offsets (<= 2^26 input floats; a slice's pitch is at most twice its channels, Cout at most four times Cin)
+        easy = (cin % 32 == 0 and cout % 32 == 0 and cout <= 4 * cin and kh <= 7 and kw <= 7 and (stride == 1 or stride == 2) and
+                x.numel() <= (1 << 26))
+        if not self.own_conv or not (easy or ops.conv_cl_supported(x, cout, (kh, kw), stride, residual, out)):
             # MIOpen + the separate epilogue pass: channel counts the MFMA tiling does not cover, operands of 2 GiB and more
             if chan_sums is not None:
                 raise RuntimeError("InferenceEngine._conv: channel sums need the own conv kernel")

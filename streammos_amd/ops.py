@@ -697,12 +697,17 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
                                   tuple(chan_sums.shape) != (b, conv_wino_sum_chunks(h, w), cout)):
         raise RuntimeError("conv_wino_cl: chan_sums must be contiguous float32 [B, conv_wino_sum_chunks(H, W), Cout], without a residual")
     lib = _lib.load()
-    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk3x3%s]" % (b, cin, h, w, cout, h, w, "+res" if residual is not None else "")
     args = (x.data_ptr(), _cl("conv_wino_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             residual.data_ptr() if residual is not None else None, _cl("conv_wino_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_wino_cl", out), b, h, w, cin, cout, int(mb), int(act),
             chan_sums.data_ptr() if chan_sums is not None else None)
     fn = lib.smos_conv_wino_cl
+    if not profiling.enabled():                      # the hot path: no label, no span
+        with _on(x.device):
+            rc = fn(*args, _stream(x))
+        _lib.check(rc, "smos_conv_wino_cl")
+        return out
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk3x3%s]" % (b, cin, h, w, cout, h, w, "+res" if residual is not None else "")
     with _on(x.device), profiling.span(label, "conv_wino"):
         rc = fn(*args, _stream(x))
     _lib.check(rc, "smos_conv_wino_cl")
@@ -1317,8 +1322,11 @@ def conv_wino1d_cl(x, wprep, bias, act, cout, kernel, mb=2, out=None):
 
 
 def empty_cl(b, c, h, w, device, zero=False):
-    make = torch.zeros if zero else torch.empty
-    return make((b, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    """logical [B, C, H, W] with channels-last strides (one allocation call; the explicit strides keep C innermost also where a
+    size-1 dimension would let torch's channels_last format choose others)"""
+    if zero:
+        return torch.zeros((b, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return torch.empty_strided((b, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.float32, device=device)
 
 
 def _cl(name, t):
