@@ -173,6 +173,7 @@ class InferenceEngine:
         self.wino1d = os.environ.get("SMOS_WINO1D", "1") != "0"  # 1-D Winograd F(2,3) for the k x 3 / 3 x k layers (A/B switch)
         self.pool_fused = os.environ.get("SMOS_POOL_FUSED", "1") != "0"   # DownSample2D pool branch + tail in one launch (A/B switch)
         self._wprep = {}
+        self._wino_plan = {}
         self._shapes = None
         self._lsi = None
         self._hw = None
@@ -419,16 +420,15 @@ class InferenceEngine:
             return ops.bias_act_cl(y, bias, act, out=out if out is not None else y, residual=residual)
         b, _, h, wd = x.shape
         ho, wo = (h + 2 * (kh // 2) - kh) // stride + 1, (wd + 2 * (kw // 2) - kw) // stride + 1
-        if self.wino and ops.conv_wino_ok((kh, kw), stride, cin, cout):
+        if self.wino and kh == 3 and kw == 3 and stride == 1 and cin % 16 == 0 and cout % 16 == 0:      # = ops.conv_wino_ok
             # stride-1 3x3: Winograd F(2x2, 3x3) on the matrix cores (csrc/conv_wino.hip): 4 instead of 9 multiply-adds per
             # output and channel pair, fp32 throughout (weights transformed in float64 on the host); 1.35-1.7x the direct
             # kernels per layer (tools/ubench_wino.py), logits within 2e-6 of the reference's (tests/test_gpu_e2e.py)
-            mb = ops.conv_wino_mb(cout, b * ((h + 7) // 8) * ((wd + 31) // 32) * (cout // 16))
-            key = (w.data_ptr(), "wino", mb)
-            wp = self._wprep.get(key)
-            if wp is None:
-                wp = self._wprep[key] = ops.conv_wino_prepare(w, mb)
-            return ops.conv_wino_cl(x, wp, bias, act, cout, mb=mb, residual=residual, out=out, chan_sums=chan_sums)
+            plan = self._wino_plan.get(id(w))          # the folded weight tensors live as long as the engine: id() is stable
+            if plan is None:
+                mb = ops.conv_wino_mb(cout)
+                plan = self._wino_plan[id(w)] = (ops.conv_wino_prepare(w, mb), mb, w)
+            return ops.conv_wino_cl(x, plan[0], bias, act, cout, mb=plan[1], residual=residual, out=out, chan_sums=chan_sums)
         if self.wino1d and ops.conv_wino1d_ok((kh, kw), stride, cin, cout, residual, chan_sums):
             # the k x 3 / 3 x k branches of the Unbalance blocks: 1-D Winograd F(2, 3) along the 3-tap axis (csrc/conv_wino1d.hip)
             mb = ops.conv_wino_mb(cout)

@@ -703,9 +703,11 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
             chan_sums.data_ptr() if chan_sums is not None else None)
     fn = lib.smos_conv_wino_cl
     if not profiling.enabled():                      # the hot path: no label, no span
-        with _on(x.device):
-            rc = fn(*args, _stream(x))
-        _lib.check(rc, "smos_conv_wino_cl")
+        dev = x.device
+        with _on(dev):
+            rc = fn(*args, _raw_stream(_dev_index(dev)))
+        if rc:
+            _lib.check(rc, "smos_conv_wino_cl")
         return out
     label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk3x3%s]" % (b, cin, h, w, cout, h, w, "+res" if residual is not None else "")
     with _on(x.device), profiling.span(label, "conv_wino"):
@@ -1332,8 +1334,8 @@ def empty_cl(b, c, h, w, device, zero=False):
 def _cl(name, t):
     """row pitch of a channels-last [B,C,H,W] view (C innermost, rows back to back over B*H*W)."""
     b, c, h, w = t.shape
-    pitch = t.stride(3)
-    if t.stride(1) != 1 or t.stride(2) != w * pitch or (b > 1 and t.stride(0) != h * w * pitch) or pitch < c:
+    s0, s1, s2, pitch = t.stride()
+    if s1 != 1 or s2 != w * pitch or (b > 1 and s0 != h * w * pitch) or pitch < c:
         raise RuntimeError("%s: expected a channels-last [B,C,H,W] view, got shape %s strides %s" % (name, tuple(t.shape), t.stride()))
     return pitch
 
