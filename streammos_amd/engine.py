@@ -273,7 +273,7 @@ class InferenceEngine:
         table = p.__dict__.get("ws")
         if table is None:
             table = p.__dict__["ws"] = ops.new_block_scratch(self.device)     # registered: release_stream_workspaces purges it
-        key = (torch.cuda.current_stream(self.device).cuda_stream, ops._ws_namespace)
+        key = (ops._raw_stream(ops._dev_index(self.device)), ops._ws_namespace)
         ws = table.get(key)
         if ws is None or ws.numel() < n_floats:
             ws = table[key] = torch.zeros(n_floats, dtype=torch.float32, device=self.device)
@@ -367,6 +367,8 @@ class InferenceEngine:
         """MIOpen solver search (measure every applicable solver once per conv shape, then reuse the fastest) --
         what the reference's own test scripts switch on (test_StreamMOS.py:20-23).  +7 % scans/s at the val shape;
         scoped to the engine's calls instead of flipping the process-wide flag."""
+        if self.own_conv and self.layout == "cl":
+            return ops._NO_GUARD          # every convolution of this engine is an own kernel: nothing for MIOpen to search
         return torch.backends.cudnn.flags(enabled=True, benchmark=self.miopen_search)
 
     def encode(self, point_feat, pcds_coord, pcds_sphere_coord, n_live=None):

@@ -75,7 +75,7 @@ def _require_cuda(name, *tensors):
 def _flag(device):
     """4-byte "saw a negative feature" scratch of the scatter; one per (device, stream) so that launches on different
     HIP streams never share it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, _ws_namespace)
+    key = (device, _raw_stream(_dev_index(device)), _ws_namespace)
     ws = _flag_ws.get(key)
     if ws is None:
         ws = torch.zeros(4, dtype=torch.int32, device=device)
@@ -1044,7 +1044,7 @@ def _stream_workspace(tag, shape, dtype, device, zero=False):
     the host has enqueued ahead of the GPU.  The returned view is valid until the next request with the same tag on the
     same stream (callers consume it within the frame).  zero=True: zero-filled when (re)allocated -- for buffers whose
     users leave them zero (the occupancy flags).  ``release_stream_workspaces`` frees them."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, dtype, _ws_namespace)
+    key = (str(device), _raw_stream(_dev_index(device)), tag, dtype, _ws_namespace)
     need = 1
     for d in shape:
         need *= int(d)
