@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import ops, profiling
+from . import ops
 
 RELU, LEAKY, NONE = ops.ACT_RELU, ops.ACT_LEAKY, ops.ACT_NONE
 
@@ -430,8 +430,6 @@ class InferenceEngine:
             if plan is None:
                 mb = ops.conv_wino_mb(cout)
                 plan = self._wino_plan[id(w)] = (ops.conv_wino_prepare(w, mb), mb, w)
-            if not profiling.enabled():
-                return ops.conv_wino_enqueue(x, plan[0], bias, act, cout, plan[1], residual, out, chan_sums)
             return ops.conv_wino_cl(x, plan[0], bias, act, cout, mb=plan[1], residual=residual, out=out, chan_sums=chan_sums)
         if self.wino1d and ops.conv_wino1d_ok((kh, kw), stride, cin, cout, residual, chan_sums):
             # the k x 3 / 3 x k branches of the Unbalance blocks: 1-D Winograd F(2, 3) along the 3-tap axis (csrc/conv_wino1d.hip)

@@ -6,7 +6,6 @@ torch is used for device memory and streams only: every function launches on
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 from . import _lib, profiling
@@ -266,15 +265,13 @@ def vote_accumulate_frames(frames, table, recip_quantize=False):
             raise RuntimeError("vote_accumulate_frames: one contiguous label per point")
         pts[f], lab[f], n[f], stride[f] = points.data_ptr(), labels.data_ptr(), points.shape[0], points.stride(0)
         if pose_diff is not None:
-            arr = np.ascontiguousarray(pose_diff, dtype=np.float64).reshape(-1)
-            if arr.size < 16:
-                raise RuntimeError("vote_accumulate_frames: pose_diff must be 4x4")
-            keep.append(arr)                          # the numpy buffer is read during the call
-            pose[f] = arr.ctypes.data_as(_lib.c_f64p)
+            arr = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
+            keep.append(arr)
+            pose[f] = ctypes.cast(arr, _lib.c_f64p)
     lib = _lib.load()
     with _on(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
         rc = lib.smos_vote_accumulate_frames(count, pts, n, stride, lab, pose, 1 if recip_quantize else 0, table.data_ptr(),
-                                             _stream(table))
+                                             torch.cuda.current_stream(table.device).cuda_stream)
     _lib.check(rc, "smos_vote_accumulate_frames")
 
 
@@ -723,44 +720,6 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
             with _on(keep[0].device), profiling.span(label, "conv_wino"):
                 _lib.check(fn(*args, _stream(keep[0])), "smos_conv_wino_cl")
         profiling.offer_replay(label, again)
-    return out
-
-
-def conv_wino_enqueue(x, wprep, bias, act, cout, mb, residual, out, chan_sums):
-    """conv_wino_cl for the engine's own maps while nothing is being profiled: same launch, without the per-launch operand
-    walk -- the engine built every view it passes (channels-last slices of its own buffers, a weight block made by
-    conv_wino_prepare for this very weight), so only what memory safety needs is looked at here (shapes, unit channel
-    stride); smos_conv_wino_cl itself rejects channel counts it does not tile."""
-    b, cin, h, w = x.shape
-    sx = x.stride()
-    if out is None:
-        out = torch.empty_strided((b, cout, h, w), (h * w * cout, 1, w * cout, cout), dtype=torch.float32, device=x.device)
-        po = cout
-    else:
-        so = out.stride()
-        po = so[3]
-        if out.shape != (b, cout, h, w) or so[1] != 1 or so[2] != w * po:
-            raise RuntimeError("conv_wino_cl: out has shape %s strides %s" % (tuple(out.shape), so))
-    if sx[1] != 1 or sx[2] != w * sx[3] or wprep.numel() != 16 * cout * cin:
-        raise RuntimeError("conv_wino_cl: unsupported operands %s strides %s -> %d" % (tuple(x.shape), sx, cout))
-    pr, res = 0, None
-    if residual is not None:
-        sr = residual.stride()
-        pr, res = sr[3], residual.data_ptr()
-        if residual.shape != (b, cout, h, w) or sr[1] != 1 or sr[2] != w * pr or chan_sums is not None:
-            raise RuntimeError("conv_wino_cl: residual has shape %s strides %s" % (tuple(residual.shape), sr))
-    sums = None
-    if chan_sums is not None:
-        sums = chan_sums.data_ptr()
-        if chan_sums.shape != (b, conv_wino_sum_chunks(h, w), cout) or not chan_sums.is_contiguous():
-            raise RuntimeError("conv_wino_cl: chan_sums must be contiguous float32 [B, conv_wino_sum_chunks(H, W), Cout]")
-    dev = x.device
-    with _on(dev):
-        rc = _lib.load().smos_conv_wino_cl(x.data_ptr(), sx[3], wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           res, pr, out.data_ptr(), po, b, h, w, cin, cout, mb, act, sums,
-                                           _raw_stream(_dev_index(dev)))
-    if rc:
-        _lib.check(rc, "smos_conv_wino_cl")
     return out
 
 
