@@ -6,6 +6,7 @@ torch is used for device memory and streams only: every function launches on
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import _lib, profiling
@@ -265,13 +266,15 @@ def vote_accumulate_frames(frames, table, recip_quantize=False):
             raise RuntimeError("vote_accumulate_frames: one contiguous label per point")
         pts[f], lab[f], n[f], stride[f] = points.data_ptr(), labels.data_ptr(), points.shape[0], points.stride(0)
         if pose_diff is not None:
-            arr = _lib.f64_array([float(v) for v in pose_diff.reshape(-1)[:16]])
-            keep.append(arr)
-            pose[f] = ctypes.cast(arr, _lib.c_f64p)
+            arr = np.ascontiguousarray(pose_diff, dtype=np.float64).reshape(-1)
+            if arr.size < 16:
+                raise RuntimeError("vote_accumulate_frames: pose_diff must be 4x4")
+            keep.append(arr)                          # the numpy buffer is read during the call
+            pose[f] = arr.ctypes.data_as(_lib.c_f64p)
     lib = _lib.load()
     with _on(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
         rc = lib.smos_vote_accumulate_frames(count, pts, n, stride, lab, pose, 1 if recip_quantize else 0, table.data_ptr(),
-                                             torch.cuda.current_stream(table.device).cuda_stream)
+                                             _stream(table))
     _lib.check(rc, "smos_vote_accumulate_frames")
 
 
