@@ -444,6 +444,18 @@ int smos_channel_gate_apply_cl(const float* y, int64_t y_pitch, const float* bia
                                const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
                                int64_t out_pitch, const float* chan_sums, int64_t chunks, float* gate_ws, int64_t B, int64_t C,
                                int64_t Cr, int64_t HW, smos_stream_t stream);
+/* BasicBlock.forward (networks/backbone.py:136-159: conv3x3-BN-ReLU, conv3x3-BN, optional ChannelAtt gate, + x, ReLU) on
+ * channels-last maps as ONE foreign call: enqueues smos_conv_wino_cl twice (+ smos_channel_gate_apply_cl when gw1 != NULL) on
+ * `stream` -- the same launches with the same arguments as the separate calls, so results are bit-identical; what is saved is
+ * the host's per-call marshalling (csrc/blocks.hip).  u1 / u2: the Winograd weight blocks of the two convs (BN folded,
+ * ops.conv_wino_prepare, same mb); b1 / b2 their biases; gw1 [Cr, C], gb1 [Cr], gw2 [C, Cr], gb2 [C]: the gate MLP or all NULL;
+ * y: scratch map [B,H,W,*] (pitch y_pitch) for the first conv's output; out may not alias x or y; ws: smos_basic_block_ws_floats
+ * floats of scratch, needed with a gate only.  Shape limits are those of smos_conv_wino_cl with Cin == Cout == C. */
+int64_t smos_basic_block_ws_floats(int64_t B, int64_t H, int64_t W, int64_t C);
+int smos_basic_block_cl(const float* x, int64_t x_pitch, const float* u1, const float* b1, const float* u2, const float* b2,
+                        const float* gw1, const float* gb1, const float* gw2, const float* gb2, int64_t Cr, float* y,
+                        int64_t y_pitch, float* out, int64_t out_pitch, float* ws, int64_t B, int64_t H, int64_t W, int64_t C,
+                        int32_t mb, smos_stream_t stream);
 int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
                             const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
                             smos_stream_t stream);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "smos_conv_rows_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp],
     "smos_conv_wino_sum_chunks": [i64, i64],
     "smos_conv_wino_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp],
+    "smos_basic_block_ws_floats": [i64, i64, i64, i64],
+    "smos_basic_block_cl": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_tfusion_project": [i32, ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],
@@ -107,6 +109,7 @@ def load():
     lib.smos_stem_scan_state_words.restype = ctypes.c_int64
     lib.smos_conv_cl_sum_chunks.restype = ctypes.c_int64
     lib.smos_conv_wino_sum_chunks.restype = ctypes.c_int64
+    lib.smos_basic_block_ws_floats.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_tfusion_layer_param_floats.restype = ctypes.c_int64
     lib.smos_tfusion_layer_stream_floats.restype = ctypes.c_int64

@@ -726,6 +726,65 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
     return out
 
 
+class BasicBlockPlan:
+    """Operands of one BasicBlock (networks/backbone.py:136-159) for smos_basic_block_cl: the two Winograd weight blocks, the
+    biases and, for a ChannelAtt block, the gate MLP -- device addresses taken once (the tensors are kept alive here)."""
+    __slots__ = ("c", "mb", "gated", "cr", "ptrs", "_keep")
+
+    def __init__(self, w1, b1, w2, b2, gate=None):
+        c = w1.shape[0]
+        if tuple(w1.shape) != (c, c, 3, 3) or tuple(w2.shape) != (c, c, 3, 3) or c % 16:
+            raise RuntimeError("BasicBlockPlan: two [C, C, 3, 3] weights with C %% 16 == 0 expected, got %s / %s"
+                               % (tuple(w1.shape), tuple(w2.shape)))
+        _require_cuda("BasicBlockPlan", w1, b1, w2, b2, *(gate or ()))
+        self.c, self.mb = c, conv_wino_mb(c)
+        u1, u2 = conv_wino_prepare(w1, self.mb), conv_wino_prepare(w2, self.mb)
+        b1, b2 = b1.float().contiguous(), b2.float().contiguous()
+        self.gated = gate is not None
+        g = [t.float().contiguous() for t in gate] if self.gated else []
+        if self.gated and (tuple(g[0].shape) != (g[0].shape[0], c) or tuple(g[2].shape) != (c, g[0].shape[0])):
+            raise RuntimeError("BasicBlockPlan: gate MLP must be [Cr, C], [Cr], [C, Cr], [C]")
+        self.cr = g[0].shape[0] if self.gated else 0
+        self._keep = (u1, b1, u2, b2, g)
+        self.ptrs = (u1.data_ptr(), b1.data_ptr(), u2.data_ptr(), b2.data_ptr()) + \
+            (tuple(t.data_ptr() for t in g) if self.gated else (None, None, None, None)) + (self.cr,)
+
+
+def basic_block_ok(c, gated):
+    """Channel counts smos_basic_block_cl takes in the engine (those of the gate kernel where the block has one)."""
+    return c % 16 == 0 and (not gated or (c % 32 == 0 and c <= 256 and 1024 % c == 0))
+
+
+def basic_block_cl(x, plan, y=None, out=None, ws=None):
+    """BasicBlock.forward on a channels-last [B,C,H,W] view in one foreign call (csrc/blocks.hip): the launches of
+    conv_wino_cl, conv_wino_cl [, channel_gate_apply_cl] with the same arguments, bit-identical results.  y: scratch map for the
+    first conv (allocated if None); ws: >= smos_basic_block_ws_floats floats for a gated block."""
+    _require_cuda("basic_block_cl", x, y, out, ws)
+    b, c, h, w = x.shape
+    if c != plan.c:
+        raise RuntimeError("basic_block_cl: %d channels, the block has %d" % (c, plan.c))
+    dev = x.device
+    if y is None:
+        y = empty_cl(b, c, h, w, dev)
+    if out is None:
+        out = empty_cl(b, c, h, w, dev)
+    if y.shape != x.shape or out.shape != x.shape:
+        raise RuntimeError("basic_block_cl: y / out must have x's shape %s" % (tuple(x.shape),))
+    lib = _lib.load()
+    wsp = None
+    if plan.gated:
+        if ws is None or ws.dtype != torch.float32 or not ws.is_contiguous() or ws.numel() < lib.smos_basic_block_ws_floats(b, h, w, c):
+            raise RuntimeError("basic_block_cl: a gated block needs smos_basic_block_ws_floats floats of contiguous scratch")
+        wsp = ws.data_ptr()
+    with _on(dev):
+        rc = lib.smos_basic_block_cl(x.data_ptr(), _cl("basic_block_cl", x), *plan.ptrs, y.data_ptr(), _cl("basic_block_cl", y),
+                                     out.data_ptr(), _cl("basic_block_cl", out), wsp, b, h, w, c, plan.mb,
+                                     _raw_stream(_dev_index(dev)))
+    if rc:
+        _lib.check(rc, "smos_basic_block_cl")
+    return out
+
+
 def msda_fwd_qp(value, qp, h, w, points):
     """value [N, H*W, M, 32] contiguous, qp [N, H*W, M*P*3] contiguous (offsets | logits) -> [N, H*W, M*32]."""
     _require_cuda("msda_fwd_qp", value, qp)

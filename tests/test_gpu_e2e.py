@@ -166,6 +166,33 @@ def test_engine_variants_agree(model):
             assert (m0 - m1).abs().max().item() <= 5e-5 * m0.abs().max().item()      # observed 1.5e-5 (behind two LayerNorms)
 
 
+def test_block_call_is_bit_identical(model):
+    """BasicBlocks enqueued by one foreign call each (smos_basic_block_cl, csrc/blocks.hip) against the launch-by-launch path:
+    the same launches with the same arguments -- logits and recurrent memory equal bit for bit over two streamed frames."""
+    frames = list(cases.e2e_frames(2))
+    model.fast_inference, model.engine_layout = True, "cl"
+    with torch.no_grad():
+        eng = model._engine_for(torch.zeros(1, device=DEV))
+    assert eng.block_call                                   # the default
+    outs = []
+    try:
+        for on in (True, False):
+            eng.block_call = on
+            memory, res = None, []
+            with torch.no_grad():
+                for i, batch in enumerate(frames):
+                    tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+                    pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+                    res.append((pred.clone(), memory.clone()))
+            outs.append(res)
+    finally:
+        eng.block_call = True
+    plans = [p.__dict__.get("plan") for p in eng.res2 if p.kind == "basic"]
+    assert plans and all(plans) and any(pl.gated for pl in plans)        # the third stage did go through the block call
+    for (p0, m0), (p1, m1) in zip(*outs):
+        assert torch.equal(p0, p1) and torch.equal(m0, m1)
+
+
 @pytest.mark.parametrize("fill", ["lidar", "empty_sample", "dense_corner"])
 def test_sparse_stem_equals_dense_downsample(model, fill):
     """header_bev[0] computed on the occupied cells only (stem_mark + per-parity-class GEMMs + stem_epilogue) against

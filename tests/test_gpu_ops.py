@@ -1105,6 +1105,49 @@ def test_conv_wino_cl_channel_sums_and_the_gate_built_on_them(cin, cout, hw, mb)
     assert (got.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("c,hw,gated,sliced", [(32, (24, 40), False, False), (64, (13, 45), True, False), (128, (16, 32), True, True),
+                                               (16, (9, 33), False, True)])
+def test_basic_block_cl_equals_the_separate_launches(c, hw, gated, sliced):
+    """smos_basic_block_cl (csrc/blocks.hip) = conv_wino_cl, conv_wino_cl [, channel_gate_apply_cl] behind one foreign call:
+    bit-identical to the separate calls, also with x / out as channel slices of wider maps; aliasing y with out is refused."""
+    gen = torch.Generator(device="cpu").manual_seed(211)
+    b, (h, w) = 2, hw
+    wide = torch.randn((b, h, w, 2 * c), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    x = wide[:, c:] if sliced else wide[:, :c].contiguous(memory_format=torch.channels_last)
+    w1, w2 = ((torch.randn((c, c, 3, 3), generator=gen) * (2.0 / (c * 9)) ** 0.5).to(DEV) for _ in range(2))
+    b1, b2 = (torch.randn(c, generator=gen).to(DEV) * 0.2 for _ in range(2))
+    gate = None
+    if gated:
+        cr = c // 4
+        gate = ((torch.randn((cr, c), generator=gen) * 0.3).to(DEV), torch.randn(cr, generator=gen).to(DEV),
+                (torch.randn((c, cr), generator=gen) * 0.3).to(DEV), torch.randn(c, generator=gen).to(DEV))
+    assert ops.basic_block_ok(c, gated)
+    plan = ops.BasicBlockPlan(w1, b1, w2, b2, gate)
+    mb = plan.mb
+    u1, u2 = ops.conv_wino_prepare(w1, mb), ops.conv_wino_prepare(w2, mb)
+    y = ops.conv_wino_cl(x, u1, b1, ops.ACT_RELU, c, mb=mb)
+    if gated:
+        chunks = ops.conv_wino_sum_chunks(h, w)
+        sums = torch.empty((b, chunks, c), device=DEV)
+        t = ops.conv_wino_cl(y, u2, None, ops.ACT_NONE, c, mb=mb, chan_sums=sums)
+        want = ops.channel_gate_apply_cl(t, b2, *gate, x, sums, torch.empty(b * c, device=DEV))
+    else:
+        want = ops.conv_wino_cl(y, u2, b2, ops.ACT_RELU, c, mb=mb, residual=x)
+    ws = torch.empty(b * c * (ops.conv_wino_sum_chunks(h, w) + 1), device=DEV) if gated else None
+    dst = torch.full((b, h, w, 3 * c), 5.0, device=DEV).permute(0, 3, 1, 2)
+    out = dst[:, c:2 * c] if sliced else None
+    got = ops.basic_block_cl(x, plan, out=out, ws=ws)
+    assert torch.equal(got, want)
+    if sliced:
+        assert float((dst[:, :c] - 5.0).abs().max()) == 0.0 and float((dst[:, 2 * c:] - 5.0).abs().max()) == 0.0
+    scratch = ops.empty_cl(b, c, h, w, DEV)
+    with pytest.raises(RuntimeError):
+        ops.basic_block_cl(x, plan, y=scratch, out=scratch, ws=ws)
+    if gated:
+        with pytest.raises(RuntimeError):
+            ops.basic_block_cl(x, plan)                      # no scratch for the channel sums
+
+
 def _tf_layer_weights(gen, ffn, nq):
     def lin(o, i):
         return ((torch.randn((o, i), generator=gen) / i ** 0.5).to(DEV), (torch.randn(o, generator=gen) * 0.3).to(DEV))
