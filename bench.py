@@ -973,14 +973,36 @@ def main():
         # configs[4]: every rank of the group trains (real DDP over RCCL when world > 1); rank 0 reports
         runner = dev_frames = None            # the inference buffers are not needed any more
         torch.cuda.empty_cache()
+        guard = None
+        if rank == 0 and world > 1:
+            # never lose the headline line to the side measurement: an exception is caught below, but a rank that dies inside
+            # the DDP step leaves the others waiting in a collective until the backend's own timeout (10 minutes and an abort).
+            # Rank 0 then reports what it has and leaves.
+            import threading
+            limit = float(os.environ.get("SMOS_BENCH_TRAIN_LIMIT_S", "420"))
+
+            def give_up():
+                line["stage2_training"] = {"error": "no result within %.0f s (a rank stuck in a collective?); the inference "
+                                                    "figures above were complete before the training step started" % limit}
+                print(json.dumps(line), flush=True)
+                os._exit(0)
+            guard = threading.Timer(limit, give_up)
+            guard.daemon = True
+            guard.start()
         try:
             res = train_bench(device, args.train_steps)
-        except Exception as e:          # never lose the headline line to the side measurement
+        except Exception as e:
             res = {"error": repr(e)[:300]}
+        if guard is not None:
+            guard.cancel()
         if rank == 0:
             line["stage2_training"] = res
     if world > 1:
         import torch.distributed as dist
+        if rank == 0 and "error" in (line.get("stage2_training") or {}):
+            # a failed training step may have left other ranks inside a collective: tearing the group down could wait for them
+            print(json.dumps(line), flush=True)
+            os._exit(0)
         dist.destroy_process_group()
     if rank == 0:
         if args.cpu_scans > 0:
