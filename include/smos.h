@@ -456,6 +456,14 @@ int smos_basic_block_cl(const float* x, int64_t x_pitch, const float* u1, const 
                         const float* gw1, const float* gb1, const float* gw2, const float* gb2, int64_t Cr, float* y,
                         int64_t y_pitch, float* out, int64_t out_pitch, float* ws, int64_t B, int64_t H, int64_t W, int64_t C,
                         int32_t mb, smos_stream_t stream);
+/* Unbalance_BasicBlock.forward (networks/multi_view_encoder.py:478-497) as one foreign call: smos_conv_wino1d_cl for the
+ * (kha x kwa) and (khb x kwb) branches into channels [0, C) and [C, 2C) of `both` (ReLU), then smos_conv_wino_cl 2C -> C over
+ * `both` with residual x and ReLU into out.  ua / ub = ops.conv_wino1d_prepare, uc = ops.conv_wino_prepare, all with the same mb.
+ * Same launches and arguments as the separate calls (bit-identical). */
+int smos_unbalance_block_cl(const float* x, int64_t x_pitch, const float* ua, const float* ba, int64_t kha, int64_t kwa,
+                            const float* ub, const float* bb, int64_t khb, int64_t kwb, const float* uc, const float* bc,
+                            float* both, int64_t both_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W,
+                            int64_t C, int32_t mb, smos_stream_t stream);
 int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
                             const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
                             smos_stream_t stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "smos_conv_wino_cl": [vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp],
     "smos_basic_block_ws_floats": [i64, i64, i64, i64],
     "smos_basic_block_cl": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp],
+    "smos_unbalance_block_cl": [vp, i64, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_tfusion_project": [i32, ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],

@@ -26,3 +26,18 @@ extern "C" int smos_basic_block_cl(const float* x, int64_t x_pitch, const float*
   return smos_channel_gate_apply_cl(out, out_pitch, b2, gw1, gb1, gw2, gb2, x, x_pitch, out, out_pitch, ws, chunks,
                                     ws + B * chunks * C, B, C, Cr, H * W, stream);
 }
+
+// Unbalance_BasicBlock.forward (networks/multi_view_encoder.py:478-497): the k x 3 and 3 x k branches into the two halves of
+// `both` (ReLU), then the 3x3 over their concatenation + x, ReLU.  Three launches (smos_conv_wino1d_cl x 2, smos_conv_wino_cl).
+extern "C" int smos_unbalance_block_cl(const float* x, int64_t x_pitch, const float* ua, const float* ba, int64_t kha, int64_t kwa,
+                                       const float* ub, const float* bb, int64_t khb, int64_t kwb, const float* uc, const float* bc,
+                                       float* both, int64_t both_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H,
+                                       int64_t W, int64_t C, int32_t mb, smos_stream_t stream) {
+  SMOS_REQUIRE(x && ua && ub && uc && both && out && both != out && x != both && x != out && both_pitch >= 2 * C,
+               "unbalance_block_cl: null pointer, aliasing maps, or `both` narrower than 2 C channels");
+  int rc = smos_conv_wino1d_cl(x, x_pitch, ua, ba, both, both_pitch, B, H, W, C, C, kha, kwa, mb, 1, stream);
+  if (rc) return rc;
+  rc = smos_conv_wino1d_cl(x, x_pitch, ub, bb, both + C, both_pitch, B, H, W, C, C, khb, kwb, mb, 1, stream);
+  if (rc) return rc;
+  return smos_conv_wino_cl(both, both_pitch, uc, bc, x, x_pitch, out, out_pitch, B, H, W, 2 * C, C, mb, 1, nullptr, stream);
+}

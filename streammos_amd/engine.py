@@ -474,6 +474,14 @@ class InferenceEngine:
             return ops.downsample_epilogue_cl(a, q, p.bias, p.stride, out=out if out is not None else a)
         if p.kind == "unbalance":
             b, c, h, w = x.shape
+            if self.block_call and self.own_conv and self.wino and self.wino1d and not profiling.enabled():
+                plan = p.__dict__.get("plan")
+                if plan is None:
+                    ok = (c % 16 == 0 and tuple(p.wc.shape) == (c, 2 * c, 3, 3) and
+                          ops.conv_wino1d_ok(tuple(p.wa.shape[2:]), 1, c, c) and ops.conv_wino1d_ok(tuple(p.wb.shape[2:]), 1, c, c))
+                    plan = p.__dict__["plan"] = ops.UnbalanceBlockPlan(p.wa, p.ba, p.wb, p.bb, p.wc, p.bc) if ok else False
+                if plan and 2 * x.numel() <= (1 << 26):
+                    return ops.unbalance_block_cl(x, plan, out=out)
             both = ops.empty_cl(b, 2 * c, h, w, x.device)
             self._conv(x, p.wa, p.ba, RELU, out=both[:, :c])
             self._conv(x, p.wb, p.bb, RELU, out=both[:, c:])

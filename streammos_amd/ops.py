@@ -159,7 +159,7 @@ def bilinear_gather(grid, coord, scale, out=None, point_major=False):
         else:
             out = torch.empty((b, c, n), dtype=torch.float32, device=grid.device)
     lib = _lib.load()
-    with _on(grid.device), profiling.span("bilinear_gather[%dx%dx%dx%d->%d]" % (b, c, h, w, n)):
+    with _on(grid.device), profiling.span_f("bilinear_gather[%dx%dx%dx%d->%d]", (b, c, h, w, n)):
         rc = lib.smos_bilinear_gather_fwd(grid.data_ptr(), _lib.i64_array(grid.stride()), coord.data_ptr(), k,
                                           out.data_ptr(), _lib.i64_array(out.stride()[:3]), b, c, h, w, n,
                                           _lib.f32_array(scale), _stream(grid))
@@ -179,7 +179,7 @@ def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
     lq, l, p = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
     out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
     lib = _lib.load()
-    with _on(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+    with _on(value.device), profiling.span_f("msda_fwd[%dx%dx%dx%d]", (n, lq, m, d)):
         rc = lib.smos_msda_fwd(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), n, s, m, d, l, lq, p,
                                _dtype_code("ms_deform_attn_forward", value), _stream(value))
@@ -199,7 +199,7 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
     g_loc = torch.empty_like(sampling_loc)
     g_attn = torch.empty_like(attn_weight)
     lib = _lib.load()
-    with _on(value.device), profiling.span("msda_bwd[%dx%dx%dx%d]" % (n, lq, m, d)):
+    with _on(value.device), profiling.span_f("msda_bwd[%dx%dx%dx%d]", (n, lq, m, d)):
         rc = lib.smos_msda_bwd(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                sampling_loc.data_ptr(), attn_weight.data_ptr(), g_value.data_ptr(), g_loc.data_ptr(),
                                g_attn.data_ptr(), n, s, m, d, l, lq, p, _dtype_code("ms_deform_attn_backward", value),
@@ -272,7 +272,7 @@ def vote_accumulate_frames(frames, table, recip_quantize=False):
             keep.append(arr)                          # the numpy buffer is read during the call
             pose[f] = arr.ctypes.data_as(_lib.c_f64p)
     lib = _lib.load()
-    with _on(table.device), profiling.span("vote_accumulate[%dx%d]" % (count, max(n))):
+    with _on(table.device), profiling.span_f("vote_accumulate[%dx%d]", (count, max(n))):
         rc = lib.smos_vote_accumulate_frames(count, pts, n, stride, lab, pose, 1 if recip_quantize else 0, table.data_ptr(),
                                              _stream(table))
     _lib.check(rc, "smos_vote_accumulate_frames")
@@ -446,7 +446,7 @@ def pointnet_scatter(xyzi, coord, w1, b1, w2, b2, bev, pts_out=None, zero_fill=F
     if pts_out is not None:
         po_b, po_n = _rows("pointnet_scatter", pts_out, cout)
     lib = _lib.load()
-    with _on(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, h, w)):
+    with _on(xyzi.device), profiling.span_f("pointnet_scatter[%dx%dx%d->%dx%d]", (b, t, n, h, w)):
         if zero_fill:
             bev.zero_()
         rc = lib.smos_pointnet_scatter(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
@@ -498,7 +498,7 @@ def point_head(rows, wprep, m3, out=None, n_live=None):
     if out is None:
         out = torch.empty((b, m3, n), dtype=torch.float32, device=rows.device)
     lib = _lib.load()
-    with _on(rows.device), profiling.span("point_head[%dx%d]" % (b, n)):
+    with _on(rows.device), profiling.span_f("point_head[%dx%d]", (b, n)):
         rc = lib.smos_point_head_live(rows.data_ptr(), rows.stride(1), wprep.data_ptr(), out.data_ptr(), b, n, 192, 96, 64, m3,
                                       n_live.data_ptr() if n_live is not None else None, _stream(rows))
     _lib.check(rc, "smos_point_head_live")
@@ -629,7 +629,8 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
                                   tuple(chan_sums.shape) != (b, conv_sum_chunks(ho, wo), cout)):
         raise RuntimeError("conv_cl: chan_sums must be contiguous float32 [B, conv_sum_chunks(Ho, Wo), Cout], without a residual")
     lib = _lib.load()
-    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, ho, wo, kh, kw, "+res" if residual is not None else "")
+    label = ("conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d%s]" % (b, cin, h, w, cout, ho, wo, kh, kw, "+res" if residual is not None else "")
+             if profiling.enabled() else None)
     args = (x.data_ptr(), _cl("conv_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             residual.data_ptr() if residual is not None else None, _cl("conv_cl", residual) if residual is not None else 0,
             out.data_ptr(), _cl("conv_cl", out), b, h, w, cin, cout, kh, kw, stride, ph, pw, mt, int(act),
@@ -637,7 +638,7 @@ def conv_cl(x, wprep, bias, act, cout, kernel, stride=1, padding=None, mt=1, res
     with _on(x.device), profiling.span(label, "conv_igemm"):
         rc = lib.smos_conv_cl(*args, _stream(x))
     _lib.check(rc, "smos_conv_cl")
-    if profiling._replay_label == label:
+    if label is not None and profiling._replay_label == label:
         keep = (x, wprep, bias, residual, out, chan_sums)          # the closure keeps the operands alive
 
         def again(keep=keep):
@@ -750,6 +751,50 @@ class BasicBlockPlan:
             (tuple(t.data_ptr() for t in g) if self.gated else (None, None, None, None)) + (self.cr,)
 
 
+class UnbalanceBlockPlan:
+    """Operands of one Unbalance_BasicBlock (networks/multi_view_encoder.py:478-497) for smos_unbalance_block_cl."""
+    __slots__ = ("c", "mb", "ptrs_a", "ptrs_b", "ptrs_c", "_keep")
+
+    def __init__(self, wa, ba, wb, bb, wc, bc):
+        c = wa.shape[0]
+        ka, kb = tuple(wa.shape[2:]), tuple(wb.shape[2:])
+        if (tuple(wa.shape[:2]) != (c, c) or tuple(wb.shape[:2]) != (c, c) or tuple(wc.shape) != (c, 2 * c, 3, 3) or
+                not conv_wino1d_ok(ka, 1, c, c) or not conv_wino1d_ok(kb, 1, c, c)):
+            raise RuntimeError("UnbalanceBlockPlan: unexpected weights %s %s %s" % (tuple(wa.shape), tuple(wb.shape), tuple(wc.shape)))
+        _require_cuda("UnbalanceBlockPlan", wa, ba, wb, bb, wc, bc)
+        self.c, self.mb = c, conv_wino_mb(c)
+        ua, ub = conv_wino1d_prepare(wa, self.mb), conv_wino1d_prepare(wb, self.mb)
+        uc = conv_wino_prepare(wc, self.mb)
+        ba, bb, bc = (t.float().contiguous() for t in (ba, bb, bc))
+        self._keep = (ua, ub, uc, ba, bb, bc)
+        self.ptrs_a = (ua.data_ptr(), ba.data_ptr(), ka[0], ka[1])
+        self.ptrs_b = (ub.data_ptr(), bb.data_ptr(), kb[0], kb[1])
+        self.ptrs_c = (uc.data_ptr(), bc.data_ptr())
+
+
+def unbalance_block_cl(x, plan, both=None, out=None):
+    """Unbalance_BasicBlock.forward on a channels-last [B,C,H,W] view in one foreign call (csrc/blocks.hip): conv_wino1d_cl x 2
+    into the halves of `both` [B,2C,H,W], conv_wino_cl over it + x.  Bit-identical to the separate calls."""
+    _require_cuda("unbalance_block_cl", x, both, out)
+    b, c, h, w = x.shape
+    if c != plan.c:
+        raise RuntimeError("unbalance_block_cl: %d channels, the block has %d" % (c, plan.c))
+    dev = x.device
+    if both is None:
+        both = empty_cl(b, 2 * c, h, w, dev)
+    if out is None:
+        out = empty_cl(b, c, h, w, dev)
+    if both.shape != (b, 2 * c, h, w) or out.shape != x.shape:
+        raise RuntimeError("unbalance_block_cl: both must be [B,2C,H,W] and out have x's shape %s" % (tuple(x.shape),))
+    with _on(dev):
+        rc = _lib.load().smos_unbalance_block_cl(x.data_ptr(), _cl("unbalance_block_cl", x), *plan.ptrs_a, *plan.ptrs_b, *plan.ptrs_c,
+                                                 both.data_ptr(), _cl("unbalance_block_cl", both), out.data_ptr(),
+                                                 _cl("unbalance_block_cl", out), b, h, w, c, plan.mb, _raw_stream(_dev_index(dev)))
+    if rc:
+        _lib.check(rc, "smos_unbalance_block_cl")
+    return out
+
+
 def basic_block_ok(c, gated):
     """Channel counts smos_basic_block_cl takes in the engine (those of the gate kernel where the block has one)."""
     return c % 16 == 0 and (not gated or (c % 32 == 0 and c <= 256 and 1024 % c == 0))
@@ -793,7 +838,7 @@ def msda_fwd_qp(value, qp, h, w, points):
         raise RuntimeError("msda_fwd_qp: expected contiguous float32 value [N,H*W,M,D] and qp [N,H*W,M*P*3]")
     out = torch.empty((n, s, m * d), dtype=torch.float32, device=value.device)
     lib = _lib.load()
-    with _on(value.device), profiling.span("msda_fwd[%dx%dx%dx%d]" % (n, s, m, d)):
+    with _on(value.device), profiling.span_f("msda_fwd[%dx%dx%dx%d]", (n, s, m, d)):
         rc = lib.smos_msda_fwd_qp(value.data_ptr(), qp.data_ptr(), out.data_ptr(), n, h, w, m, d, points, _stream(value))
     _lib.check(rc, "smos_msda_fwd_qp")
     return out
@@ -925,7 +970,8 @@ def tfusion_project(jobs):
         bs[j] = bias.data_ptr() if bias is not None else None
     lib = _lib.load()
     x0 = jobs[0][0]
-    label = "tfusion_project[%s]" % ",".join("%dx128->%d" % (int(toks[j]), int(couts[j])) for j in range(n))
+    label = ("tfusion_project[%s]" % ",".join("%dx128->%d" % (int(toks[j]), int(couts[j])) for j in range(n))
+             if profiling.enabled() else None)
     with _on(x0.device), profiling.span(label):
         rc = lib.smos_tfusion_project(n, xs, pit, ws, bs, outs, ops_, couts, toks, _stream(x0))
     _lib.check(rc, "smos_tfusion_project")
@@ -948,7 +994,7 @@ def tfusion_layer(sampled, query, prep, out=None):
         raise RuntimeError("tfusion_layer: out must hold [tokens, 128]")
     nxt = torch.empty((tokens, prep.nq), dtype=torch.float32, device=sampled.device) if prep.nq else None
     lib = _lib.load()
-    with _on(sampled.device), profiling.span("tfusion_layer[%dx128x%d%s]" % (tokens, prep.ffn, "+q%d" % prep.nq if prep.nq else "")):
+    with _on(sampled.device), profiling.span_f("tfusion_layer[%dx128x%d%s]", (tokens, prep.ffn, "+q%d" % prep.nq if prep.nq else "")):
         rc = lib.smos_tfusion_layer(sampled.data_ptr(), query.data_ptr(), qp, prep.stream.data_ptr(), prep.params.data_ptr(),
                                     out.data_ptr(), op, nxt.data_ptr() if nxt is not None else None, prep.nq, tokens, prep.ffn,
                                     prep.eps1, prep.eps2, _stream(sampled))
@@ -1060,20 +1106,21 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
             if fused:
                 continue
             t = torch.empty((b, 3, hs, wo, c), dtype=torch.float32, device=conv_a.device)
-            with profiling.span("upconv_xpass[%dx%dx%dx%d->%d]" % (b, hs, ws, c, wo)):
+            with profiling.span_f("upconv_xpass[%dx%dx%dx%d->%d]", (b, hs, ws, c, wo)):
                 _lib.check(lib.smos_upconv_xpass(z.data_ptr(), t.data_ptr(), b, hs, ws, c, wo, st), "smos_upconv_xpass")
             ts.append((t, hs))
         if fused:
             z1, h1, w1 = zs[0]
             z2, h2, w2 = zs[1] if len(zs) > 1 else (None, 0, 0)
-            with profiling.span("upconv_xy[%dx%dx%dx%d<-%s]" % (b, ho, wo, c, "+".join("%dx%d" % (h, w) for _, h, w in zs))):
+            with profiling.span("upconv_xy[%dx%dx%dx%d<-%s]" % (b, ho, wo, c, "+".join("%dx%d" % (h, w) for _, h, w in zs))
+                                if profiling.enabled() else None):
                 _lib.check(lib.smos_upconv_xy(conv_a.data_ptr(), _cl("upconv3x3", conv_a), bias.data_ptr(), z1.data_ptr(), h1, w1,
                                               z2.data_ptr() if z2 is not None else None, h2, w2, out.data_ptr(), _cl("upconv3x3", out),
                                               b, ho, wo, c, int(act), st), "smos_upconv_xy")
             return out
         t1, h1 = ts[0]
         t2, h2 = ts[1] if len(ts) > 1 else (None, 0)
-        with profiling.span("upconv_ypass[%dx%dx%dx%d]" % (b, ho, wo, c)):
+        with profiling.span_f("upconv_ypass[%dx%dx%dx%d]", (b, ho, wo, c)):
             _lib.check(lib.smos_upconv_ypass(conv_a.data_ptr(), _cl("upconv3x3", conv_a), bias.data_ptr(), t1.data_ptr(), h1,
                                              t2.data_ptr() if t2 is not None else None, h2, out.data_ptr(), _cl("upconv3x3", out),
                                              b, ho, wo, c, int(act), st), "smos_upconv_ypass")
@@ -1211,7 +1258,7 @@ def stem_plan(coord, h, w, row_floats=0):
         # capacity: an occupied cell holds at least one point, so min(cells, points) rows always suffice
         rows = _stream_workspace("stem_rows", (min(cells, b * t * n), row_floats), torch.float32, dev)
     st = _stream(coord)
-    with _on(dev), profiling.span("stem_mark+scan[%dx%dx%d]" % (b, h, w)):
+    with _on(dev), profiling.span_f("stem_mark+scan[%dx%dx%d]", (b, h, w)):
         _lib.check(lib.smos_stem_mark(coord.data_ptr(), k, b, t, n, h, w, flags.data_ptr(), state.data_ptr(), st), "smos_stem_mark")
         _lib.check(lib.smos_stem_scan(flags.data_ptr(), b, h, w, state.data_ptr(), row_cell.data_ptr(), row_of.data_ptr(),
                                       meta.data_ptr(), rows.data_ptr() if rows is not None else None, row_floats, st), "smos_stem_scan")
@@ -1239,7 +1286,7 @@ def pointnet_scatter_rows(xyzi, coord, w1, b1, w2, b2, plan, pts_out=None, n_liv
     lib = _lib.load()
     st = _stream(xyzi)
     # the span holds exactly ONE kernel, so its HIP-event mean is comparable with rocprofv3's per-kernel mean
-    with _on(xyzi.device), profiling.span("pointnet_scatter[%dx%dx%d->%dx%d]" % (b, t, n, plan.h, plan.w)):
+    with _on(xyzi.device), profiling.span_f("pointnet_scatter[%dx%dx%d->%dx%d]", (b, t, n, plan.h, plan.w)):
         rc = lib.smos_pointnet_scatter_rows_live(xyzi.data_ptr(), coord.data_ptr(), k, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                                  b2.data_ptr(), rows.data_ptr(), plan.row_of.data_ptr(),
                                                  pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, t, n,
@@ -1271,7 +1318,7 @@ def sparse_downsample(src, plan, wprep, bias, compact, out=None):
     w_ptrs = (ctypes.c_void_p * 4)(*[wt.data_ptr() for wt in wprep])
     lib = _lib.load()
     st = _stream(src)
-    tag = "[%dx%dx%dx%d]" % (b, h, w, cin)
+    tag = "[%dx%dx%dx%d]" % (b, h, w, cin) if profiling.enabled() else ""
     with _on(dev):
         with profiling.span("stem_gemm" + tag):
             _lib.check(lib.smos_stem_gemm(src.data_ptr(), None if compact else plan.row_cell.data_ptr(), plan.meta.data_ptr(),
@@ -1368,14 +1415,14 @@ def conv_wino1d_cl(x, wprep, bias, act, cout, kernel, mb=2, out=None):
     elif tuple(out.shape) != (b, cout, h, w):
         raise RuntimeError("conv_wino1d_cl: out has shape %s" % (tuple(out.shape),))
     lib = _lib.load()
-    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d]" % (b, cin, h, w, cout, h, w, kh, kw)
+    label = "conv_cl[%dx%dx%dx%d->%dx%dx%dk%dx%d]" % (b, cin, h, w, cout, h, w, kh, kw) if profiling.enabled() else None
     args = (x.data_ptr(), _cl("conv_wino1d_cl", x), wprep.data_ptr(), bias.data_ptr() if bias is not None else None,
             out.data_ptr(), _cl("conv_wino1d_cl", out), b, h, w, cin, cout, kh, kw, int(mb), int(act))
     fn = lib.smos_conv_wino1d_cl
     with _on(x.device), profiling.span(label, "conv_wino1d"):
         rc = fn(*args, _stream(x))
     _lib.check(rc, "smos_conv_wino1d_cl")
-    if profiling._replay_label == label:
+    if label is not None and profiling._replay_label == label:
         keep = (x, wprep, bias, out)
 
         def again(keep=keep):
@@ -1457,7 +1504,7 @@ def downsample_pool_branch(x, wpairs, a, bias, stride, out=None):
     elif tuple(out.shape) != (b, c, ho, wo):
         raise RuntimeError("downsample_pool_branch: out has shape %s" % (tuple(out.shape),))
     lib = _lib.load()
-    with _on(x.device), profiling.span("downsample_pool_branch[%dx%dx%dx%d/s%d]" % (b, c, h, w, stride)):
+    with _on(x.device), profiling.span_f("downsample_pool_branch[%dx%dx%dx%d/s%d]", (b, c, h, w, stride)):
         rc = lib.smos_downsample_pool_branch(x.data_ptr(), _cl("downsample_pool_branch", x), wpairs.data_ptr(), a.data_ptr(),
                                              _cl("downsample_pool_branch", a), bias.data_ptr(), out.data_ptr(),
                                              _cl("downsample_pool_branch", out), b, h, w, c, c, int(stride), _stream(x))
@@ -1535,8 +1582,9 @@ def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, 
     if pts_out is not None:
         po_b, po_n = _rows("gather_scatter_cl", pts_out, c)
     lib = _lib.load()
-    label = "gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d%s]" % (b, c, hg, wg, n, ho, wo,
-                                                          "+pts" if pts_out is not None and out is not None else "")
+    label = ("gather_scatter_cl[%dx%dx%dx%d->%d->%dx%d%s]" % (b, c, hg, wg, n, ho, wo,
+                                                           "+pts" if pts_out is not None and out is not None else "")
+             if profiling.enabled() else None)
     with _on(grid.device), profiling.span(label):
         rc = lib.smos_gather_scatter_cl_live(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
                                              _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,

@@ -76,6 +76,13 @@ def span(label, family=None):
     return _active.span(label, family)
 
 
+def span_f(fmt, args, family=None):
+    """span(fmt % args, family) with the formatting left out while nothing is being timed (the per-step launches)."""
+    if _active is None:
+        return _NULL
+    return span(fmt % args, family)
+
+
 def request_replay(label):
     """Ask ops to keep the next launch carrying `label` (bench.py re-runs the dominant kernel alone on the GPU)."""
     global _replay_label

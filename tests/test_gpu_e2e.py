@@ -189,6 +189,9 @@ def test_block_call_is_bit_identical(model):
         eng.block_call = True
     plans = [p.__dict__.get("plan") for p in eng.res2 if p.kind == "basic"]
     assert plans and all(plans) and any(pl.gated for pl in plans)        # the third stage did go through the block call
+    unb = [p.__dict__.get("plan") for stage in (eng.header_bev, eng.header_rv, eng.res1_bev, eng.res1_rv, eng.res2)
+           for p in stage if p.kind == "unbalance"]
+    assert unb and all(unb)                                              # and so did the Unbalance blocks
     for (p0, m0), (p1, m1) in zip(*outs):
         assert torch.equal(p0, p1) and torch.equal(m0, m1)
 

@@ -1148,6 +1148,29 @@ def test_basic_block_cl_equals_the_separate_launches(c, hw, gated, sliced):
             ops.basic_block_cl(x, plan)                      # no scratch for the channel sums
 
 
+@pytest.mark.parametrize("c,hw,k", [(32, (24, 40), 7), (64, (13, 45), 5)])
+def test_unbalance_block_cl_equals_the_separate_launches(c, hw, k):
+    """smos_unbalance_block_cl = conv_wino1d_cl (k x 3), conv_wino1d_cl (3 x k), conv_wino_cl (2C -> C, + x) behind one foreign
+    call: bit-identical to the separate calls."""
+    gen = torch.Generator(device="cpu").manual_seed(223)
+    b, (h, w) = 2, hw
+    x = torch.randn((b, h, w, c), generator=gen).to(DEV).permute(0, 3, 1, 2)
+    wa = (torch.randn((c, c, k, 3), generator=gen) * (2.0 / (c * 3 * k)) ** 0.5).to(DEV)
+    wb = (torch.randn((c, c, 3, k), generator=gen) * (2.0 / (c * 3 * k)) ** 0.5).to(DEV)
+    wc = (torch.randn((c, 2 * c, 3, 3), generator=gen) * (1.0 / (c * 9)) ** 0.5).to(DEV)
+    ba, bb, bc = (torch.randn(c, generator=gen).to(DEV) * 0.2 for _ in range(3))
+    plan = ops.UnbalanceBlockPlan(wa, ba, wb, bb, wc, bc)
+    mb = plan.mb
+    both = ops.empty_cl(b, 2 * c, h, w, DEV)
+    ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(wa, mb), ba, ops.ACT_RELU, c, (k, 3), mb=mb, out=both[:, :c])
+    ops.conv_wino1d_cl(x, ops.conv_wino1d_prepare(wb, mb), bb, ops.ACT_RELU, c, (3, k), mb=mb, out=both[:, c:])
+    want = ops.conv_wino_cl(both, ops.conv_wino_prepare(wc, mb), bc, ops.ACT_RELU, c, mb=mb, residual=x)
+    got = ops.unbalance_block_cl(x, plan)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        ops.unbalance_block_cl(x, plan, both=ops.empty_cl(b, c, h, w, DEV))      # `both` too narrow
+
+
 def _tf_layer_weights(gen, ffn, nq):
     def lin(o, i):
         return ((torch.randn((o, i), generator=gen) / i ** 0.5).to(DEV), (torch.randn(o, generator=gen) * 0.3).to(DEV))
