@@ -50,8 +50,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   const int per_block = (a.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nb = (int)gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = (int)blockIdx.x & 7;
   const int lblock = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
-  const int first = lblock * per_block;
-  const int iters = a.n_items - first < per_block ? a.n_items - first : per_block;
+  // Two item orders.  a.group == 0: the block owns a contiguous item range, cout tile fastest (a block stages a region once per
+  // cout tile, nct times in a row).  a.group == 1 (grid a multiple of nct): nct consecutive blocks -- same XCD, dispatched
+  // together, equal work -- walk the SAME regions in step, one cout tile each: the region's second .. nct-th reader finds it in
+  // the L2 the first one just filled instead of fetching it again many chunks later, and a block cycles through one cout
+  // tile's weight slices only.  With one item per block the two orders are the same assignment.
+  const int regions = a.n_items / a.nct;
+  const int ngrp = nb / a.nct;
+  const int grp = lblock / a.nct, ctm = lblock - grp * a.nct;
+  const int per_group = a.group ? (regions + ngrp - 1) / ngrp : 0;
+  const int first = a.group ? grp * per_group : lblock * per_block;          // first region / first item
+  const int left = (a.group ? regions : a.n_items) - first, mine = a.group ? per_group : per_block;
+  const int iters = left < mine ? left : mine;
   if (iters <= 0) return;
   const int total = iters * a.nchunk;
 
@@ -61,8 +71,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   auto first_item = [&]() {
     WinoItem t;
     int u = first;
-    t.ct = u % a.nct;
-    u /= a.nct;
+    if (a.group) {
+      t.ct = ctm;
+    } else {
+      t.ct = u % a.nct;
+      u /= a.nct;
+    }
     t.x0 = (u % a.xb) * 32;
     u /= a.xb;
     t.y0 = (u % a.yb) * 8;
@@ -71,10 +85,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   };
   auto next_item = [&](const WinoItem& t) {
     WinoItem n = t;
-    const bool w_ct = t.ct + 1 == a.nct;
+    const bool w_ct = a.group ? true : t.ct + 1 == a.nct;
     const bool w_x = w_ct & (t.x0 + 32 >= a.xb * 32);
     const bool w_y = w_x & (t.y0 + 8 >= a.yb * 8);
-    n.ct = w_ct ? 0 : t.ct + 1;
+    n.ct = a.group ? t.ct : (w_ct ? 0 : t.ct + 1);
     n.x0 = w_x ? 0 : t.x0 + (w_ct ? 32 : 0);
     n.y0 = w_y ? 0 : t.y0 + (w_x ? 8 : 0);
     n.b = t.b + (w_y ? 1 : 0);
@@ -175,8 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
   // see at all), so the wait that matters is explicit: before the
   // barrier that ends k-step s, everything but the requests issued during k-step s itself has landed (vmcnt retires in
   // order), i.e. the slice k-step s + 1 reads ----
-  const int n_slices = a.nct * a.nchunk * 4;
-  int pa_slice = (first % a.nct) * a.nchunk * 4;
+  // (group order: the block's one cout tile, cyclically)
+  const int slice_lo = a.group ? ctm * a.nchunk * 4 : 0;
+  const int n_slices = a.group ? slice_lo + a.nchunk * 4 : a.nct * a.nchunk * 4;
+  int pa_slice = a.group ? slice_lo : (first % a.nct) * a.nchunk * 4;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 #define WINO_W_LOAD(so)                                                                                          \
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino(WinoArgs a) {
       __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)d_, 16, 0, 0);                                        \
       if constexpr (MB > 1) __builtin_amdgcn_global_load_lds((gptr_t)(s_ + 256), (lptr_t)(d_ + 256), 16, 0, 0);  \
     }                                                                                                            \
-    pa_slice = pa_slice + 1 == n_slices ? 0 : pa_slice + 1;                                                      \
+    pa_slice = pa_slice + 1 == n_slices ? slice_lo : pa_slice + 1;                                               \
   } while (0)
 #define WINO_VM_WAIT(n)                                                   \
   do {                                                                    \
@@ -472,8 +488,18 @@ static int launch_wino(const WinoArgs& a, hipStream_t s) {
   }();
   const int per_cu = ks.per_cu < want_per_cu ? ks.per_cu : want_per_cu;
   const int64_t cap = conv_grid_cap((int64_t)ks.cus * per_cu);
-  const unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
-  hipLaunchKernelGGL((conv_wino<MB, RES, SUMS>), dim3(grid), dim3(256), lds, s, a);
+  unsigned grid = (unsigned)(a.n_items < cap ? a.n_items : cap);
+  static const bool want_group = [] {
+    const char* e = getenv("SMOS_WINO_CT_GROUP");
+    return !(e && e[0] == '0');
+  }();
+  WinoArgs b = a;
+  b.group = 0;
+  if (want_group && a.nct > 1 && grid >= (unsigned)a.nct) {
+    grid -= grid % (unsigned)a.nct;          // n_items is a multiple of nct, so an uncapped grid already is
+    b.group = 1;
+  }
+  hipLaunchKernelGGL((conv_wino<MB, RES, SUMS>), dim3(grid), dim3(256), lds, s, b);
   return check_launch("conv_wino_cl");
 }
 

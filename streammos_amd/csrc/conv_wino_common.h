@@ -31,6 +31,7 @@ struct WinoArgs {
   int n_items;         // B * yb * xb * nct
   float slope;         // activation: max(v, 0) + slope * min(v, 0)
   int x_bytes, r_bytes, o_bytes, cout;
+  int group;           // item order: 0 = contiguous item range per block, 1 = nct consecutive blocks share a region range (conv_wino.hip)
 };
 
 constexpr int kWPP = 17;                          // words per staged pixel: 16 channels + 1 (odd pitch)
