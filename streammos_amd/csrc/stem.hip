@@ -147,85 +147,114 @@ __global__ __launch_bounds__(kBlock) void stem_scan(int32_t* __restrict__ flags,
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kStemK = 192, kStemSteps = kStemK / 2, kStemBlock = 512;
 
-template <int kM>
-__device__ __forceinline__ void stem_gemm_class(const float* __restrict__ bev, const int32_t* __restrict__ row_cell,
-                                                const int32_t* __restrict__ meta, int cls, const float* __restrict__ wprep,
-                                                float* __restrict__ y, float* lds_w, int block, int n_blocks) {
-  for (int i = threadIdx.x; i < kM * kStemSteps * 64; i += kStemBlock) lds_w[i] = wprep[i];   // [kM][96][64]
-  __syncthreads();
-  const int start = meta[4 + cls], n = meta[8 + cls] - start;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+// One 32-cell tile x NM blocks of 32 output channels starting at block mt0: acc[NM], the cells' 192 values streamed in four
+// K-quarters (the next quarter's 6 float4 of the row are in flight while the current one feeds the matrix core; keeping all 96
+// row values live at once spills under the 256-register budget).  ldy = the class's row length (kM * 32).
+template <int NM>
+__device__ __forceinline__ void stem_tile(const float* __restrict__ bev, const int32_t* __restrict__ row_cell, int start, int n,
+                                          int tile, int mt0, int ldy, const float* lds_w, float* __restrict__ y, int lane) {
   const int col = lane & 31, hh = lane >> 5;
-  constexpr int kWaves = kStemBlock / 64;
-  for (int tile = block * kWaves + wave; tile * 32 < n; tile += n_blocks * kWaves) {
-    const int r = tile * 32 + col;
-    const bool valid = r < n;
-    // row_cell == null: bev already IS the compact row table (smos_pointnet_scatter_rows), row = start + r
-    const int32_t cell = valid ? (row_cell ? row_cell[start + r] : start + r) : 0;
-    const float4* src = reinterpret_cast<const float4*>(bev + (int64_t)cell * kStemK + hh * kStemSteps);
-    // K in four quarters of 24 steps: the next quarter's 6 float4 of the row are in flight while the current quarter
-    // feeds the matrix core (keeping all 96 row values live at once spills under the 256-register budget)
-    constexpr int kQ = 4, kQSteps = kStemSteps / kQ;
-    float4 cur[kQSteps / 4], nxt[kQSteps / 4];
+  const int r = tile * 32 + col;
+  const bool valid = r < n;
+  // row_cell == null: bev already IS the compact row table (smos_pointnet_scatter_rows), row = start + r
+  const int32_t cell = valid ? (row_cell ? row_cell[start + r] : start + r) : 0;
+  const float4* src = reinterpret_cast<const float4*>(bev + (int64_t)cell * kStemK + hh * kStemSteps);
+  constexpr int kQ = 4, kQSteps = kStemSteps / kQ;
+  float4 cur[kQSteps / 4], nxt[kQSteps / 4];
 #pragma unroll
-    for (int j = 0; j < kQSteps / 4; ++j) cur[j] = src[j];
-    f32x16 acc[kM];
+  for (int j = 0; j < kQSteps / 4; ++j) cur[j] = src[j];
+  f32x16 acc[NM];
 #pragma unroll
-    for (int mt = 0; mt < kM; ++mt)
+  for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+    for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
 #pragma unroll 1
-    for (int qt = 0; qt < kQ; ++qt) {
-      if (qt + 1 < kQ) {
+  for (int qt = 0; qt < kQ; ++qt) {
+    if (qt + 1 < kQ) {
 #pragma unroll
-        for (int j = 0; j < kQSteps / 4; ++j) nxt[j] = src[(qt + 1) * (kQSteps / 4) + j];
-      }
-      const float* wq = lds_w + (qt * kQSteps) * 64 + lane;
-#pragma unroll
-      for (int s = 0; s < kQSteps; ++s) {
-        const float4 v = cur[s >> 2];
-        const float b = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
-#pragma unroll
-        for (int mt = 0; mt < kM; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kStemSteps + s) * 64], b, acc[mt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < kQSteps / 4; ++j) cur[j] = nxt[j];
+      for (int j = 0; j < kQSteps / 4; ++j) nxt[j] = src[(qt + 1) * (kQSteps / 4) + j];
     }
-    if (valid) {
-      float* dst = y + (int64_t)r * (kM * 32) + 4 * hh;
+    const float* wq = lds_w + (mt0 * kStemSteps + qt * kQSteps) * 64 + lane;
 #pragma unroll
-      for (int mt = 0; mt < kM; ++mt)
+    for (int s = 0; s < kQSteps; ++s) {
+      const float4 v = cur[s >> 2];
+      const float b = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(dst + mt * 32 + 8 * g) =
-              make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+      for (int mt = 0; mt < NM; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kStemSteps + s) * 64], b, acc[mt], 0, 0, 0);
     }
+#pragma unroll
+    for (int j = 0; j < kQSteps / 4; ++j) cur[j] = nxt[j];
+  }
+  if (valid) {
+    float* dst = y + (int64_t)r * ldy + mt0 * 32 + 4 * hh;
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + mt * 32 + 8 * g) =
+            make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
   }
 }
 
-// ONE launch for the four parity classes: the blocks are split between the classes in proportion to their work
-// (equal row counts by symmetry, 2 : 3 : 3 : 5 output blocks), every block keeps its class's weights in LDS.
+// A wave's share [lo, hi) of a class's work units (unit u = (tile u / kM, output block u % kM)): whole tiles with all kM
+// accumulators, the ragged head and tail one output block at a time.
+template <int kM>
+__device__ __forceinline__ void stem_units(const float* __restrict__ bev, const int32_t* __restrict__ row_cell, int start, int n,
+                                           int lo, int hi, const float* lds_w, float* __restrict__ y, int lane) {
+  int u = lo;
+  for (; u < hi && u % kM != 0; ++u) stem_tile<1>(bev, row_cell, start, n, u / kM, u % kM, kM * 32, lds_w, y, lane);
+  for (; u + kM <= hi; u += kM) stem_tile<kM>(bev, row_cell, start, n, u / kM, 0, kM * 32, lds_w, y, lane);
+  for (; u < hi; ++u) stem_tile<1>(bev, row_cell, start, n, u / kM, u % kM, kM * 32, lds_w, y, lane);
+}
+
+// ONE launch for the four parity classes.  Work unit = (32-cell tile, 32 output channels) = 96 MFMAs; the units of the four
+// classes form one list (class 0 first) that is cut into equal contiguous ranges per block and, inside a block, per wave --
+// from the DEVICE-side row counts (meta), so the split follows the frame's real occupancy and every wave gets the same number
+// of units +- 1.  (Until r04 the blocks were split 2 : 3 : 3 : 5 between the classes and a wave took whole tiles: with 2.2
+// tiles of 5 output blocks per wave in the largest class, the slowest SIMD carried 30 units against a mean of 21.5.)  A block
+// keeps the weights of the class it works on in LDS; the few blocks whose range crosses a class boundary reload them once.
 struct StemGemmArgs {
   const float* bev;
   const int32_t* row_cell;
   const int32_t* meta;
   const float* wprep[4];
   float* y[4];
-  int first_block[5];
 };
 
 __global__ __launch_bounds__(kStemBlock) void stem_gemm(StemGemmArgs a) {
   extern __shared__ float lds_w[];
-  const int bid = blockIdx.x;
-  if (bid < a.first_block[1])
-    stem_gemm_class<2>(a.bev, a.row_cell, a.meta, 0, a.wprep[0], a.y[0], lds_w, bid - a.first_block[0], a.first_block[1] - a.first_block[0]);
-  else if (bid < a.first_block[2])
-    stem_gemm_class<3>(a.bev, a.row_cell, a.meta, 1, a.wprep[1], a.y[1], lds_w, bid - a.first_block[1], a.first_block[2] - a.first_block[1]);
-  else if (bid < a.first_block[3])
-    stem_gemm_class<3>(a.bev, a.row_cell, a.meta, 2, a.wprep[2], a.y[2], lds_w, bid - a.first_block[2], a.first_block[3] - a.first_block[2]);
-  else
-    stem_gemm_class<5>(a.bev, a.row_cell, a.meta, 3, a.wprep[3], a.y[3], lds_w, bid - a.first_block[3], a.first_block[4] - a.first_block[3]);
+  constexpr int kMs[4] = {2, 3, 3, 5};
+  int start[4], n[4], units[4];
+  int64_t total = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    start[c] = a.meta[4 + c];
+    n[c] = a.meta[8 + c] - start[c];
+    units[c] = ((n[c] + 31) / 32) * kMs[c];
+    total += units[c];
+  }
+  const int64_t b_lo = total * blockIdx.x / gridDim.x, b_hi = total * (blockIdx.x + 1) / gridDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  constexpr int kWaves = kStemBlock / 64;
+  int64_t base = 0;
+  bool loaded = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t lo = b_lo > base ? b_lo : base, hi = b_hi < base + units[c] ? b_hi : base + units[c];
+    if (lo < hi) {                                         // block-uniform
+      if (loaded) __syncthreads();                         // every wave is done with the previous class's weights
+      for (int i = threadIdx.x; i < kMs[c] * kStemSteps * 64; i += kStemBlock) lds_w[i] = a.wprep[c][i];   // [kM][96][64]
+      __syncthreads();
+      loaded = true;
+      const int l = (int)(lo - base), len = (int)(hi - lo);
+      const int w_lo = l + (int)((int64_t)len * wave / kWaves), w_hi = l + (int)((int64_t)len * (wave + 1) / kWaves);
+      if (c == 0) stem_units<2>(a.bev, a.row_cell, start[c], n[c], w_lo, w_hi, lds_w, a.y[c], lane);
+      else if (c == 3) stem_units<5>(a.bev, a.row_cell, start[c], n[c], w_lo, w_hi, lds_w, a.y[c], lane);
+      else stem_units<3>(a.bev, a.row_cell, start[c], n[c], w_lo, w_hi, lds_w, a.y[c], lane);
+    }
+    base += units[c];
+  }
 }
 
 struct StemEpiArgs {
@@ -354,16 +383,8 @@ extern "C" int smos_stem_gemm(const float* bev, const int32_t* row_cell, const i
     a.wprep[c] = wprep4[c];
     a.y[c] = y4[c];
   }
-  // one block per CU (120 KB of LDS); shares 2 : 3 : 3 : 5 of at least one block each
-  const int blocks = cus < 4 ? 4 : cus;
-  const int share[4] = {2, 3, 3, 5};
-  int at = 0;
-  for (int c = 0; c < 4; ++c) {
-    a.first_block[c] = at;
-    int nb = blocks * share[c] / 13;
-    at += nb < 1 ? 1 : nb;
-  }
-  a.first_block[4] = at;
+  // one block per CU (120 KB of LDS); the kernel splits the work from the device-side row counts
+  const int at = cus < 1 ? 1 : cus;
   hipLaunchKernelGGL(stem_gemm, dim3(at), dim3(kStemBlock), lds, (hipStream_t)stream, a);
   return check_launch("stem_gemm");
 }

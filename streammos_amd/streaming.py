@@ -10,6 +10,7 @@ Sequences are independent streams: multi-GPU inference as
 ranks (``shard_sequences``) and needs no collective.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -201,7 +202,7 @@ def concurrent_stream(device, candidates=8, spin_cycles=400000):
         best, best_t = None, float("inf")
         keep = []                                    # hold the rejected streams until the choice is made (no handle reuse)
         for _ in range(candidates):
-            cand = torch.cuda.Stream(device)
+            cand = torch.cuda.Stream(device, priority=int(os.environ.get("SMOS_SIDE_PRIORITY", "0")))
             keep.append(cand)
             t = min(run([main, cand]) for _ in range(2))
             if t < best_t:
