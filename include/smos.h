@@ -464,6 +464,11 @@ int smos_unbalance_block_cl(const float* x, int64_t x_pitch, const float* ua, co
                             const float* ub, const float* bb, int64_t khb, int64_t kwb, const float* uc, const float* bc,
                             float* both, int64_t both_pitch, float* out, int64_t out_pitch, int64_t B, int64_t H, int64_t W,
                             int64_t C, int32_t mb, smos_stream_t stream);
+/* Zero fill of n <= 4 channels-last views (rows[i] rows of row_floats[i] floats at pitch pitches[i], 16-byte aligned) in one
+ * launch: the zero-initialised scatter-max targets of the cross-view transfers (networks/multi_view_encoder.py:395-420 create
+ * theirs with torch.zeros inside VoxelMaxPool, deep_point/point_deep.py:27). */
+int smos_zero_views_cl(int32_t n, float* const* ptrs, const int64_t* rows, const int64_t* row_floats, const int64_t* pitches,
+                       smos_stream_t stream);
 int smos_upsample_concat_cl(const float* const* src, const int64_t* src_c, const int64_t* src_h, const int64_t* src_w,
                             const int64_t* src_pitch, int32_t n_src, float* out, int64_t B, int64_t Ho, int64_t Wo,
                             smos_stream_t stream);
@@ -485,6 +490,14 @@ int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch, const flo
                                 const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch, float* pts_out,
                                 int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
                                 int64_t Wo, const int32_t* n_live, smos_stream_t stream);
+/* The same with the coordinates as strided views: sample b, point n at coord + b * batch_stride + n * K floats (the first two
+ * of a point's K values are read).  Lets a caller pass pcds_coord[:, 0, :, :, 0] of the reference's [B, T, N, 3, 1] tensor
+ * (networks/multi_view_encoder.py:395-420 slice it the same way) without a compacting copy. */
+int smos_gather_scatter_cl_view(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, int64_t g_batch_stride,
+                                const float* gscale, const float* scoord, int32_t Ks, int64_t s_batch_stride, const float* sscale,
+                                float* out, int64_t out_pitch, float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C,
+                                int64_t Hg, int64_t Wg, int64_t N, int64_t Ho, int64_t Wo, const int32_t* n_live,
+                                smos_stream_t stream);
 
 #ifdef __cplusplus
 }

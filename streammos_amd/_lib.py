@@ -55,6 +55,7 @@ SIGNATURES = {
     "smos_basic_block_ws_floats": [i64, i64, i64, i64],
     "smos_basic_block_cl": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp],
     "smos_unbalance_block_cl": [vp, i64, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
+    "smos_zero_views_cl": [i32, ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_tfusion_project": [i32, ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],
@@ -78,6 +79,7 @@ SIGNATURES = {
     "smos_upsample_concat_cl": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
     "smos_gather_scatter_cl": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "smos_downsample_pool_branch": [vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp],
+    "smos_gather_scatter_cl_view": [vp, i64, vp, i32, i64, c_f32p, vp, i32, i64, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp],
     "smos_gather_scatter_cl_live": [vp, i64, vp, i32, c_f32p, vp, i32, c_f32p, vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp],
     "smos_upsample_concat": [ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, i32, vp, i64, i64, i64, vp],
 }

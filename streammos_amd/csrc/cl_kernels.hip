@@ -272,12 +272,12 @@ __global__ __launch_bounds__(kBlock) void upsample_concat_cl(UpSrcCl s0, UpSrcCl
 // row atomic whenever the target cell changes (azimuth-ordered LiDAR points mostly stay in the same cell).
 struct GsClArgs {
   const float* grid;    // [B, Hg, Wg, *] row pitch gp (channel offset already applied)
-  const float* gcoord;  // [B, N, Kg]
-  const float* scoord;  // [B, N, Ks] or null
+  const float* gcoord;  // sample b, point n at gcoord + b * gbs + n * Kg (dense [B, N, Kg]: gbs = N * Kg)
+  const float* scoord;  // likewise with sbs, Ks; or null
   float* out;           // [B, Ho, Wo, *] row pitch op (channel offset applied), zero-filled; or null
   float* pts_out;       // [B, N, *] row pitch po_n (channel offset applied); or null
   const int32_t* n_live; // device, or null: point rows of the padding tail [*n_live, N) are not wanted (gather_scatter_cl4 only)
-  int64_t gp, op, po_b, po_n;
+  int64_t gp, op, po_b, po_n, gbs, sbs;
   int B, N, Kg, Ks, Hg, Wg, Ho, Wo;
   float gsy, gsx, ssy, ssx;
 };
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
     float wt[4] = {0.f, 0.f, 0.f, 0.f};
     int cell = -1;
     if (n < a.N) {
-      const float* cr = a.gcoord + ((int64_t)b * a.N + n) * a.Kg;
+      const float* cr = a.gcoord + (int64_t)b * a.gbs + (int64_t)n * a.Kg;
       const float iy = pix_cl(cr[0], a.gsy, a.Hg), ix = pix_cl(cr[1], a.gsx, a.Wg);
       const float fy = floorf(iy), fx = floorf(ix);
       const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl(GsClArgs a) {
         wt[k] = in ? w4[k] : 0.0f;
       }
       if (a.scoord) {
-        const float* sr = a.scoord + ((int64_t)b * a.N + n) * a.Ks;
+        const float* sr = a.scoord + (int64_t)b * a.sbs + (int64_t)n * a.Ks;
         const float py = __fmul_rn(sr[0], a.ssy), px = __fmul_rn(sr[1], a.ssx);
         const bool ok = (py > -1.0f) && (py < (float)a.Ho) && (px > -1.0f) && (px < (float)a.Wo);
         cell = ok ? (int)py * a.Wo + (int)px : -1;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
     float wt[4] = {0.f, 0.f, 0.f, 0.f};
     int cell = -1;
     if (n < a.N) {
-      const float* cr = a.gcoord + ((int64_t)b * a.N + n) * a.Kg;
+      const float* cr = a.gcoord + (int64_t)b * a.gbs + (int64_t)n * a.Kg;
       const float iy = pix_cl(cr[0], a.gsy, a.Hg), ix = pix_cl(cr[1], a.gsx, a.Wg);
       const float fy = floorf(iy), fx = floorf(ix);
       const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void gather_scatter_cl4(GsClArgs a) {
         wt[k] = in ? w4[k] : 0.0f;
       }
       if (kScatter) {
-        const float* sr = a.scoord + ((int64_t)b * a.N + n) * a.Ks;
+        const float* sr = a.scoord + (int64_t)b * a.sbs + (int64_t)n * a.Ks;
         const float py = __fmul_rn(sr[0], a.ssy), px = __fmul_rn(sr[1], a.ssx);
         const bool ok = (py > -1.0f) && (py < (float)a.Ho) && (px > -1.0f) && (px < (float)a.Wo);
         cell = ok ? (int)py * a.Wo + (int)px : -1;
@@ -556,6 +556,45 @@ extern "C" int smos_bias_act_cl(const float* x, int64_t x_pitch, const float* bi
   return check_launch("bias_act_cl");
 }
 
+// Zero fill of up to four channels-last views (rows x row_floats at a row pitch) in ONE launch: the scatter targets of a
+// frame's two cross-view transfers (two dense range-view maps, two channel slices of concatenation buffers).
+struct ZeroViews {
+  float* p[4];
+  int64_t rows[4], pitch[4];
+  int f4[4];          // float4 per row
+};
+
+__global__ __launch_bounds__(kBlock) void zero_views(ZeroViews a) {
+  const int v = blockIdx.y;
+  const int64_t total = a.rows[v] * a.f4[v];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / a.f4[v];
+    const int c = (int)(i - r * a.f4[v]);
+    *reinterpret_cast<float4*>(a.p[v] + r * a.pitch[v] + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+extern "C" int smos_zero_views_cl(int32_t n, float* const* ptrs, const int64_t* rows, const int64_t* row_floats, const int64_t* pitches,
+                                  smos_stream_t stream) {
+  SMOS_REQUIRE(n >= 1 && n <= 4 && ptrs && rows && row_floats && pitches, "zero_views_cl: 1 .. 4 views");
+  ZeroViews a;
+  int64_t most = 0;
+  for (int v = 0; v < 4; ++v) {
+    const int k = v < n ? v : 0;
+    SMOS_REQUIRE(ptrs[k] && al16(ptrs[k]) && rows[k] >= 0 && row_floats[k] > 0 && row_floats[k] % 4 == 0 && pitches[k] >= row_floats[k] &&
+                     pitches[k] % 4 == 0, "zero_views_cl: views must be 16-byte aligned rows of a multiple of 4 floats");
+    a.p[v] = ptrs[k];
+    a.rows[v] = v < n ? rows[k] : 0;
+    a.pitch[v] = pitches[k];
+    a.f4[v] = (int)(row_floats[k] / 4);
+    const int64_t t = a.rows[v] * a.f4[v];
+    most = t > most ? t : most;
+  }
+  if (most == 0) return SMOS_OK;
+  hipLaunchKernelGGL(zero_views, dim3(grid_for(most, kBlock, 256 * 8), n), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return check_launch("zero_views_cl");
+}
+
 extern "C" int smos_downsample_epilogue_cl(const float* a, int64_t a_pitch, const float* p, int64_t p_pitch, const float* bias,
                                            float* out, int64_t out_pitch, int64_t B, int64_t C, int64_t H, int64_t W,
                                            int32_t stride, smos_stream_t stream) {
@@ -632,10 +671,11 @@ extern "C" int smos_upsample_concat_cl(const float* const* src, const int64_t* s
   return check_launch("upsample_concat_cl");
 }
 
-extern "C" int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
-                                           const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
-                                           float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
-                                           int64_t N, int64_t Ho, int64_t Wo, const int32_t* n_live, smos_stream_t stream);
+extern "C" int smos_gather_scatter_cl_view(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, int64_t g_batch_stride,
+                                           const float* gscale, const float* scoord, int32_t Ks, int64_t s_batch_stride,
+                                           const float* sscale, float* out, int64_t out_pitch, float* pts_out, int64_t po_b,
+                                           int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
+                                           int64_t Wo, const int32_t* n_live, smos_stream_t stream);
 
 extern "C" int smos_gather_scatter_cl(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, const float* gscale,
                                       const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
@@ -651,7 +691,20 @@ extern "C" int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch
                                            const float* scoord, int32_t Ks, const float* sscale, float* out, int64_t out_pitch,
                                            float* pts_out, int64_t po_b, int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg,
                                            int64_t N, int64_t Ho, int64_t Wo, const int32_t* n_live, smos_stream_t stream) {
+  return smos_gather_scatter_cl_view(grid, grid_pitch, gcoord, Kg, N * Kg, gscale, scoord, Ks, N * Ks, sscale, out, out_pitch, pts_out,
+                                     po_b, po_n, B, C, Hg, Wg, N, Ho, Wo, n_live, stream);
+}
+
+// The coordinates as strided views: sample b, point n at coord + b * batch_stride + n * K (floats; the first two of a point's K
+// values are read) -- the engine passes pcds_coord[:, 0, :, :, 0] of the reference's [B, T, N, 3, 1] tensor as it lies, without a
+// compacting copy.  Everything else as smos_gather_scatter_cl_live.
+extern "C" int smos_gather_scatter_cl_view(const float* grid, int64_t grid_pitch, const float* gcoord, int32_t Kg, int64_t g_batch_stride,
+                                           const float* gscale, const float* scoord, int32_t Ks, int64_t s_batch_stride,
+                                           const float* sscale, float* out, int64_t out_pitch, float* pts_out, int64_t po_b,
+                                           int64_t po_n, int64_t B, int64_t C, int64_t Hg, int64_t Wg, int64_t N, int64_t Ho,
+                                           int64_t Wo, const int32_t* n_live, smos_stream_t stream) {
   SMOS_REQUIRE(B > 0 && (C == 32 || C == 64) && N > 0 && Hg > 0 && Wg > 0 && Kg >= 2, "gather_scatter_cl: bad sizes (C must be 32 or 64)");
+  SMOS_REQUIRE(g_batch_stride >= 0 && (!out || s_batch_stride >= 0), "gather_scatter_cl: negative coordinate stride");
   SMOS_REQUIRE(grid && gcoord && gscale && (out || pts_out) && grid_pitch >= C, "gather_scatter_cl: null pointer / bad pitch");
   SMOS_REQUIRE(!out || (scoord && sscale && Ks >= 2 && Ho > 0 && Wo > 0 && out_pitch >= C && Ho * Wo < (1LL << 31)),
                "gather_scatter_cl: bad scatter target");
@@ -659,7 +712,7 @@ extern "C" int smos_gather_scatter_cl_live(const float* grid, int64_t grid_pitch
   SMOS_REQUIRE(Hg * Wg < (1LL << 31), "gather_scatter_cl: grid too large");
   GsClArgs a;
   a.grid = grid; a.gcoord = gcoord; a.scoord = out ? scoord : nullptr; a.out = out; a.pts_out = pts_out; a.n_live = n_live;
-  a.gp = grid_pitch; a.op = out_pitch; a.po_b = po_b; a.po_n = po_n;
+  a.gp = grid_pitch; a.op = out_pitch; a.po_b = po_b; a.po_n = po_n; a.gbs = g_batch_stride; a.sbs = s_batch_stride;
   a.B = (int)B; a.N = (int)N; a.Kg = Kg; a.Ks = Ks; a.Hg = (int)Hg; a.Wg = (int)Wg; a.Ho = (int)Ho; a.Wo = (int)Wo;
   a.gsy = gscale[0]; a.gsx = gscale[1]; a.ssy = out ? sscale[0] : 0.f; a.ssx = out ? sscale[1] : 0.f;
   // 16-byte lanes wherever the rows are 16-byte aligned (every call of the engine); SMOS_GS_VEC=0: the one-lane-per-channel

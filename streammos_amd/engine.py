@@ -526,15 +526,16 @@ class InferenceEngine:
             x = self._block_cl(x, p, out if i == len(blocks) - 1 else None)
         return x
 
-    def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None, n_live=None):
+    def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None, n_live=None, rv=None):
         """B2P gather + P2R scatter, range-view convs, R2P gather + P2B scatter straight into cat_buf[:, c:]
         (multi_view_encoder.py:395-405 / :410-420); everything channels-last, nothing transposed."""
         b = cat_buf.shape[0]
-        rv = ops.empty_cl(b, c, rv_hw[0], rv_hw[1], cat_buf.device, zero=True)
+        back = cat_buf[:, c:]
+        if rv is None:
+            rv = ops.empty_cl(b, c, rv_hw[0], rv_hw[1], cat_buf.device)
+            ops.zero_views_cl([rv, back])                 # the two scatter-max targets
         ops.gather_scatter_cl(cat_buf[:, :c], bev_xy, scale, sphere, scale, out=rv)
         rv = self._stage_cl(rv, rv_blocks)
-        back = cat_buf[:, c:]
-        back.zero_()
         ops.gather_scatter_cl(rv, sphere, scale, bev_xy, scale, out=back, pts_out=point_rows, n_live=n_live)
 
     def _stem_sparse_cl(self, bev_cl, pcds_coord):
@@ -546,8 +547,9 @@ class InferenceEngine:
     def _encode_cl(self, point_feat, pcds_coord, pcds_sphere_coord, n_live=None):
         bs, t, cin, n, _ = point_feat.shape
         dev = point_feat.device
-        bev_xy = pcds_coord[:, 0, :, :2, 0].contiguous()
-        sphere = pcds_sphere_coord[:, 0, :, :, 0].contiguous()
+        # views, not copies: the cross-view kernels take the strided slices as they lie (smos_gather_scatter_cl_view)
+        bev_xy = pcds_coord[:, 0, :, :2, 0]
+        sphere = pcds_sphere_coord[:, 0, :, :, 0]
         cpt = self.pp2[0].shape[0]
         hb, wb = self.bev_hw
         c_dec, c1 = self.conv_2[0].shape[0], self.res1_bev[-1].w2.shape[0]
@@ -555,6 +557,11 @@ class InferenceEngine:
         fuse = torch.empty((bs, n, cpt + c_dec + c1), dtype=torch.float32, device=dev)
         c0 = self.header_bev[-1].w2.shape[0]
         x0cat = ops.empty_cl(bs, 2 * c0, hb // 2, wb // 2, dev)
+        x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
+        # the four zero-initialised scatter-max targets of the frame's two cross-view transfers (two range-view maps, the upper
+        # channel halves of the two concatenation buffers) in one launch instead of four torch fills
+        rv0, rv1 = ops.empty_cl(bs, c0, 32, 1024, dev), ops.empty_cl(bs, c1, 16, 512, dev)
+        ops.zero_views_cl([rv0, x0cat[:, c0:], rv1, x1cat[:, c1:]])
         if self.sparse_stem and self.stem_w is not None:
             # sparse first stage: the occupancy of the grid follows from the coordinates alone, so the point MLP scatters
             # into a compact row table (one row per occupied cell) and the 805 MB dense grid is never built
@@ -568,10 +575,10 @@ class InferenceEngine:
             ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
                                  pts_out=fuse[:, :, :o1], zero_fill=True)
             self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
-        self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5))
-        x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
+        self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5), rv=rv0)
         self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])
-        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:], n_live=n_live)
+        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:], n_live=n_live,
+                            rv=rv1)
         # res2 (the third BEV stage) is independent of the past too, but it runs in decode(): that keeps the two pipeline
         # stages balanced so both HIP streams stay busy (re-measured after the sparse first stage shortened the encoder:
         # res2 on the encode side 158.6 vs 167.5 scans/s)

@@ -1566,18 +1566,50 @@ def upsample_concat_cl(sources, size):
     return out
 
 
+def zero_views_cl(views):
+    """Zero fill of up to four channels-last [B,C,H,W] views (dense maps or channel slices of wider ones) in one launch."""
+    if not 1 <= len(views) <= 4:
+        raise RuntimeError("zero_views_cl: 1 .. 4 views")
+    _require_cuda("zero_views_cl", *views)
+    k = len(views)
+    ptrs, rows, rf, pit = (ctypes.c_void_p * k)(), (ctypes.c_int64 * k)(), (ctypes.c_int64 * k)(), (ctypes.c_int64 * k)()
+    for i, v in enumerate(views):
+        b, c, h, w = v.shape
+        if v.dtype != torch.float32 or v.device != views[0].device:
+            raise RuntimeError("zero_views_cl: float32 views on one device")
+        ptrs[i], rows[i], rf[i], pit[i] = v.data_ptr(), b * h * w, c, _cl("zero_views_cl", v)
+    with _on(views[0].device):
+        rc = _lib.load().smos_zero_views_cl(k, ptrs, rows, rf, pit, _stream(views[0]))
+    if rc:
+        _lib.check(rc, "smos_zero_views_cl")
+
+
+def _coord_view(name, t, b, n):
+    """(floats per point, floats per sample) of a coordinate view [B, N, K >= 2] whose last dimension is dense -- contiguous or a
+    slice of a wider tensor such as pcds_coord[:, 0, :, :, 0] of the reference's [B, T, N, 3, 1] layout."""
+    if t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != b or (n is not None and t.shape[1] != n) or t.shape[2] < 2:
+        raise RuntimeError("%s: coordinates must be float32 [B, N, K >= 2], got %s %s" % (name, tuple(t.shape), t.dtype))
+    s0, s1, s2 = t.stride()
+    if s2 != 1 or s1 < 2 or s0 < 0:
+        raise RuntimeError("%s: coordinate view with strides %s (the last dimension must be dense)" % (name, t.stride()))
+    return s1, s0
+
+
 def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, pts_out=None, n_live=None):
     """grid: channels-last [B,C,Hg,Wg] view; out: channels-last [B,C,Ho,Wo] view, zero-filled (or None);
-    pts_out: [B,N,C] rows (or None).  n_live (device int32 tensor, optional): real points at the front of every sample; point
-    rows of the padding tail are not written."""
+    pts_out: [B,N,C] rows (or None).  gcoord / scoord: [B,N,K>=2] float32 views with a dense last dimension (strided slices of
+    the reference's coordinate tensors are taken as they lie).  n_live (device int32 tensor, optional): real points at the front
+    of every sample; point rows of the padding tail are not written."""
     _require_cuda("gather_scatter_cl", grid, gcoord, scoord, out, pts_out, n_live)
     if n_live is not None and (n_live.dtype != torch.int32 or n_live.numel() < 1):
         raise RuntimeError("gather_scatter_cl: n_live must be a device int32 tensor")
     b, c, hg, wg = grid.shape
-    n, kg = gcoord.shape[1], gcoord.shape[2]
-    ho = wo = ks = op = 0
+    n = gcoord.shape[1]
+    kg, gbs = _coord_view("gather_scatter_cl", gcoord, b, None)
+    ho = wo = ks = op = sbs = 0
     if out is not None:
-        ho, wo, ks, op = out.shape[2], out.shape[3], scoord.shape[2], _cl("gather_scatter_cl", out)
+        ho, wo, op = out.shape[2], out.shape[3], _cl("gather_scatter_cl", out)
+        ks, sbs = _coord_view("gather_scatter_cl", scoord, b, n)
     po_b = po_n = 0
     if pts_out is not None:
         po_b, po_n = _rows("gather_scatter_cl", pts_out, c)
@@ -1586,10 +1618,10 @@ def gather_scatter_cl(grid, gcoord, gscale, scoord=None, sscale=None, out=None, 
                                                            "+pts" if pts_out is not None and out is not None else "")
              if profiling.enabled() else None)
     with _on(grid.device), profiling.span(label):
-        rc = lib.smos_gather_scatter_cl_live(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg,
-                                             _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks,
+        rc = lib.smos_gather_scatter_cl_view(grid.data_ptr(), _cl("gather_scatter_cl", grid), gcoord.data_ptr(), kg, gbs,
+                                             _lib.f32_array(gscale), scoord.data_ptr() if out is not None else None, ks, sbs,
                                              _lib.f32_array(sscale) if out is not None else None,
                                              out.data_ptr() if out is not None else None, op,
                                              pts_out.data_ptr() if pts_out is not None else None, po_b, po_n, b, c, hg, wg, n, ho, wo,
                                              n_live.data_ptr() if n_live is not None else None, _stream(grid))
-    _lib.check(rc, "smos_gather_scatter_cl_live")
+    _lib.check(rc, "smos_gather_scatter_cl_view")

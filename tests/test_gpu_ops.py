@@ -602,6 +602,36 @@ def test_gather_scatter_cl_float4_lanes_equal_the_one_lane_per_channel_kernel(c,
     assert res[0][0].abs().max().item() > 0 and bool((res[0][1][:, -300:] == 0).all())
 
 
+def test_gather_scatter_cl_takes_strided_coordinate_views_and_zero_views_fills_slices():
+    """smos_gather_scatter_cl_view: the coordinates as slices of the reference's [B, T, N, 3, 1] / [B, T, N, 2, 1] tensors (pitch 3,
+    batch stride T * N * 3) give what their compacted copies give, bit for bit.  smos_zero_views_cl: a dense map and a channel slice
+    of a wider one zeroed in one launch, the other half of the wide map untouched."""
+    gen = torch.Generator(device="cpu").manual_seed(47)
+    b, t, n, c, scale = 3, 3, 64 * 11 + 5, 64, 0.25
+    hw_g, hw_o = (32, 128), (16, 64)
+    grid = _to_cl(torch.relu(torch.randn((b, c) + hw_g, generator=gen)).to(DEV))
+    coord5 = torch.randn((b, t, n, 3, 1), generator=gen).to(DEV)
+    sphere5 = torch.randn((b, t, n, 2, 1), generator=gen).to(DEV)
+    coord5[:, 0, :, :2, 0] = _model_like_coords(gen, b, n, hw_g[0] / scale, hw_g[1] / scale).to(DEV)
+    sphere5[:, 0, :, :, 0] = _model_like_coords(gen, b, n, hw_o[0] / scale, hw_o[1] / scale).to(DEV)
+    gview, sview = coord5[:, 0, :, :2, 0], sphere5[:, 0, :, :, 0]
+    assert not gview.is_contiguous() and gview.stride() == (t * n * 3, 3, 1)
+    res = []
+    for g, s_ in ((gview, sview), (gview.contiguous(), sview.contiguous())):
+        wide = torch.full((b, hw_o[0], hw_o[1], 2 * c), 3.0, device=DEV).permute(0, 3, 1, 2)
+        dense = torch.full((b, hw_o[0], hw_o[1], c), 7.0, device=DEV).permute(0, 3, 1, 2)
+        ops.zero_views_cl([dense, wide[:, c:]])
+        assert float(dense.abs().max()) == 0.0 and float(wide[:, c:].abs().max()) == 0.0 and float((wide[:, :c] - 3.0).abs().max()) == 0.0
+        rows = torch.empty((b, n, c), device=DEV)
+        ops.gather_scatter_cl(grid, g, (scale, scale), s_, (scale, scale), out=wide[:, c:], pts_out=rows)
+        res.append((wide[:, c:].clone(), rows))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][0].abs().max().item() > 0
+    with pytest.raises(RuntimeError):
+        ops.gather_scatter_cl(grid, coord5[:, 0, :, :, 0].transpose(1, 2), (scale, scale), pts_out=torch.empty((b, n, c), device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.zero_views_cl([])
+
+
 @pytest.mark.parametrize("c,hw_g,hw_o,scale", [(64, (16, 512), (128, 128), 0.25), (32, (256, 256), (32, 1024), 0.5)])
 def test_gather_scatter_channels_last_full_size(c, hw_g, hw_o, scale):
     """The engine's cross-view transfers at the validation shape (4 x 160 000 points incl. the padding tail at -1000):
