@@ -198,14 +198,31 @@ __device__ __forceinline__ void stem_tile(const float* __restrict__ bev, const i
 }
 
 // A wave's share [lo, hi) of a class's work units (unit u = (tile u / kM, output block u % kM)): whole tiles with all kM
-// accumulators, the ragged head and tail one output block at a time.
+// accumulators; a ragged head or tail is ONE pass over the tile's rows with as many accumulators as it has output blocks (the
+// two waves that share a tile each read its rows once).
+template <int kM>
+__device__ __forceinline__ void stem_part(const float* __restrict__ bev, const int32_t* __restrict__ row_cell, int start, int n,
+                                          int tile, int mt0, int cnt, const float* lds_w, float* __restrict__ y, int lane) {
+  switch (cnt) {                                           // wave-uniform
+    case 1: stem_tile<1>(bev, row_cell, start, n, tile, mt0, kM * 32, lds_w, y, lane); break;
+    case 2: if constexpr (kM > 2) stem_tile<2>(bev, row_cell, start, n, tile, mt0, kM * 32, lds_w, y, lane); break;
+    case 3: if constexpr (kM > 3) stem_tile<3>(bev, row_cell, start, n, tile, mt0, kM * 32, lds_w, y, lane); break;
+    case 4: if constexpr (kM > 4) stem_tile<4>(bev, row_cell, start, n, tile, mt0, kM * 32, lds_w, y, lane); break;
+    default: break;
+  }
+}
+
 template <int kM>
 __device__ __forceinline__ void stem_units(const float* __restrict__ bev, const int32_t* __restrict__ row_cell, int start, int n,
                                            int lo, int hi, const float* lds_w, float* __restrict__ y, int lane) {
   int u = lo;
-  for (; u < hi && u % kM != 0; ++u) stem_tile<1>(bev, row_cell, start, n, u / kM, u % kM, kM * 32, lds_w, y, lane);
+  if (u < hi && u % kM != 0) {                             // head: the rest of a tile another wave started
+    const int end = (u / kM + 1) * kM < hi ? (u / kM + 1) * kM : hi;
+    stem_part<kM>(bev, row_cell, start, n, u / kM, u % kM, end - u, lds_w, y, lane);
+    u = end;
+  }
   for (; u + kM <= hi; u += kM) stem_tile<kM>(bev, row_cell, start, n, u / kM, 0, kM * 32, lds_w, y, lane);
-  for (; u < hi; ++u) stem_tile<1>(bev, row_cell, start, n, u / kM, u % kM, kM * 32, lds_w, y, lane);
+  if (u < hi) stem_part<kM>(bev, row_cell, start, n, u / kM, 0, hi - u, lds_w, y, lane);     // tail: the start of the next tile
 }
 
 // ONE launch for the four parity classes.  Work unit = (32-cell tile, 32 output channels) = 96 MFMAs; the units of the four
