@@ -145,6 +145,13 @@ __global__ __launch_bounds__(kBlock) void stem_scan(int32_t* __restrict__ flags,
 //   B operand (cells):   lane (p, h) holds channels h*96 .. h*96+95 of cell p -- 24 contiguous float4 loads of its row.
 // kM = taps + 1 blocks of 32 output channels.  The row count is read from device memory (meta): no host round trip.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Diagnostic builds only (tools/ablate_stem.sh): -DSMOS_STEM_ABLATE=<bits> removes 1 the row loads, 2 the MFMAs, 4 the Y stores
+// from stem_gemm to time what is left; results are wrong.  The shipped library is built without it.
+#ifdef SMOS_STEM_ABLATE
+#define STEM_AB(bit) ((SMOS_STEM_ABLATE) & (bit))
+#else
+#define STEM_AB(bit) 0
+#endif
 constexpr int kStemK = 192, kStemSteps = kStemK / 2, kStemBlock = 512;
 
 // One 32-cell tile x NM blocks of 32 output channels starting at block mt0: acc[NM], the cells' 192 values streamed in four
@@ -162,7 +169,7 @@ __device__ __forceinline__ void stem_tile(const float* __restrict__ bev, const i
   constexpr int kQ = 4, kQSteps = kStemSteps / kQ;
   float4 cur[kQSteps / 4], nxt[kQSteps / 4];
 #pragma unroll
-  for (int j = 0; j < kQSteps / 4; ++j) cur[j] = src[j];
+  for (int j = 0; j < kQSteps / 4; ++j) cur[j] = STEM_AB(1) ? make_float4((float)lane, 1.f, 2.f, (float)j) : src[j];
   f32x16 acc[NM];
 #pragma unroll
   for (int mt = 0; mt < NM; ++mt)
@@ -172,7 +179,8 @@ __device__ __forceinline__ void stem_tile(const float* __restrict__ bev, const i
   for (int qt = 0; qt < kQ; ++qt) {
     if (qt + 1 < kQ) {
 #pragma unroll
-      for (int j = 0; j < kQSteps / 4; ++j) nxt[j] = src[(qt + 1) * (kQSteps / 4) + j];
+      for (int j = 0; j < kQSteps / 4; ++j)
+        nxt[j] = STEM_AB(1) ? make_float4((float)lane, 1.f, (float)qt, (float)j) : src[(qt + 1) * (kQSteps / 4) + j];
     }
     const float* wq = lds_w + (mt0 * kStemSteps + qt * kQSteps) * 64 + lane;
 #pragma unroll
@@ -180,13 +188,15 @@ __device__ __forceinline__ void stem_tile(const float* __restrict__ bev, const i
       const float4 v = cur[s >> 2];
       const float b = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
 #pragma unroll
-      for (int mt = 0; mt < NM; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kStemSteps + s) * 64], b, acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < NM; ++mt) {
+        if (STEM_AB(2)) acc[mt][s & 15] += wq[(mt * kStemSteps + s) * 64] * b;
+        else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kStemSteps + s) * 64], b, acc[mt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < kQSteps / 4; ++j) cur[j] = nxt[j];
   }
-  if (valid) {
+  if (valid && !(STEM_AB(4) && acc[0][0] != 12345.678f)) {
     float* dst = y + (int64_t)r * ldy + mt0 * 32 + 4 * hh;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt)
