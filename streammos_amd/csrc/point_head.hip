@@ -42,20 +42,24 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, hh = lane >> 5;
   constexpr int kWaves = kHeadBlock / 64;
-  const int tiles_per_sample = (a.N + 31) / 32;
-  const int n_tiles = a.B * tiles_per_sample;
   const int n_live = a.n_live ? min(max(*a.n_live, 0), a.N) : a.N;
-  for (int tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
-    const int b = tile / tiles_per_sample;
-    const int n = (tile - b * tiles_per_sample) * 32 + col;
-    const bool valid = n < a.N;
-    if (n - col >= n_live) {
-      // a tile in the padding tail (datasets/data_StreamMOS.py:568-571 pads every scan to frame_point_num with points at
-      // -1000 that val_StreamMOS.py:113 cuts off again): its logits are never read; they are written as zeros
-      if (valid)
-        for (int ch = 0; ch < a.M3; ++ch) a.out[((int64_t)b * a.M3 + ch) * a.N + n] = 0.0f;
-      continue;
+  // The padding tail (datasets/data_StreamMOS.py:568-571 pads every scan to frame_point_num with points at -1000 that
+  // val_StreamMOS.py:113 cuts off again): its logits are never read; they are written as zeros, by all threads alike.  The
+  // waves then share the LIVE tiles only -- dealing out all tiles round-robin left a wave 5 to 7 live ones of its ~10.
+  const int live_tiles = (n_live + 31) / 32, tail0 = live_tiles * 32;
+  if (tail0 < a.N) {
+    const int64_t per = (int64_t)a.M3 * (a.N - tail0), total = (int64_t)a.B * per;
+    for (int64_t i = (int64_t)blockIdx.x * kHeadBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kHeadBlock) {
+      const int b = (int)(i / per);
+      const int64_t r = i - (int64_t)b * per;
+      const int ch = (int)(r / (a.N - tail0));
+      a.out[((int64_t)b * a.M3 + ch) * a.N + tail0 + (r - (int64_t)ch * (a.N - tail0))] = 0.0f;
     }
+  }
+  for (int lt = blockIdx.x * kWaves + wave; lt < a.B * live_tiles; lt += gridDim.x * kWaves) {
+    const int b = lt / live_tiles;
+    const int n = (lt - b * live_tiles) * 32 + col;
+    const bool valid = n < a.N;
     const float4* src = reinterpret_cast<const float4*>(a.rows + ((int64_t)b * a.N + (valid ? n : 0)) * a.rp + hh * kS1);
 
     // ---- layer 1: 192 -> 96, K streamed in four quarters
