@@ -149,9 +149,12 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
       const_cast<int32_t*>(a.row_of), 0, a.row_of ? (a.S / a.T) * a.H * a.W * 4 : 0, 0x00020000);
   constexpr unsigned kOob = 0x80000000u;
   auto fetch = [&](int nt, TileIn& in) {
+    // tile nt = column tile nt / S of sample nt % S (sample fastest): a wave's tiles nt, nt + step, .. then spread evenly over
+    // the point range of every sample, so every wave meets the same share of the scans' padding tails (sample-major order
+    // left a wave 15 to 20 live tiles of its 29)
     const bool live = nt < n_nt;
-    const int s = live ? nt / nt_per_sample : 0;
-    const int n0 = live ? (nt - s * nt_per_sample) * kNt : 0;
+    const int s = live ? nt % a.S : 0;
+    const int n0 = live ? (nt / a.S) * kNt : 0;
     const bool has = live & (n0 + col < a.N);
     const unsigned xoff = (unsigned)((s * 7 + hh) * a.N + n0 + col) * 4u;      // feature f = 2 q + hh of the lane's point
     const unsigned fstep = (unsigned)a.N * 8u;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
   auto cell_request = [&](const TileIn& in, int tile, int& c, int& r) {
     const float yx[2] = {in.has ? in.cy : -1.0f, in.has ? in.cx : -1.0f};   // -1 is outside the half-open test of cell_2d
     c = cell_2d(yx, 1.0f, 1.0f, a.H, a.W);
-    const unsigned roff = (c >= 0) ? (unsigned)(((tile / nt_per_sample) / a.T) * a.H * a.W + c) * 4u : kOob;
+    const unsigned roff = (c >= 0) ? (unsigned)(((tile % a.S) / a.T) * a.H * a.W + c) * 4u : kOob;
     r = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrd, roff, 0, 0);      // no row table: zero-sized buffer, reads 0
   };
   auto cell_resolve = [&](int c, int r) { return ((a.row_of != nullptr) & (c >= 0)) ? r : c; };
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(kBlock) void pointnet_scatter(PnsArgs a) {
     fetch(nt + 2 * nt_step, nn);
     int c_next, r_next;
     cell_request(nxt, nt + nt_step, c_next, r_next);
-    const int s = nt / nt_per_sample;
-    const int n0 = (nt - s * nt_per_sample) * kNt;
+    const int s = nt % a.S;
+    const int n0 = (nt / a.S) * kNt;
     const int b = s / a.T, t = s - b * a.T;
     float xk[4] = {cur.x[0], cur.x[1], cur.x[2], hh ? 1.0f : cur.x[3]};      // feature 7 = 1 carries the folded layer-1 bias
     // the shuffle is its own statement: inside the short-circuit expression it would run with lane 31 masked off, and
