@@ -14,6 +14,13 @@
 namespace smos {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Diagnostic builds only (tools/ablate_head.sh): -DSMOS_HEAD_ABLATE=<bits> removes 1 the row loads, 2 the layer-1 MFMAs, 4 layers
+// 2 / 3, 8 the logit stores to time what is left; results are wrong.  The shipped library is built without it.
+#ifdef SMOS_HEAD_ABLATE
+#define HEAD_AB(bit) ((SMOS_HEAD_ABLATE) & (bit))
+#else
+#define HEAD_AB(bit) 0
+#endif
 constexpr int kHeadBlock = 512;
 constexpr int kK1 = 192, kM1 = 96, kM2 = 64;
 constexpr int kS1 = kK1 / 2, kS2 = kM1 / 2, kS3 = kM2 / 2;           // k-steps (two k per MFMA)
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
     constexpr int kQ = 4, kQSteps = kS1 / kQ;
     float4 cur[kQSteps / 4], nxt[kQSteps / 4];
 #pragma unroll
-    for (int j = 0; j < kQSteps / 4; ++j) cur[j] = src[j];
+    for (int j = 0; j < kQSteps / 4; ++j) cur[j] = HEAD_AB(1) ? make_float4((float)lane, 1.f, 2.f, (float)j) : src[j];
     f32x16 c1[kM1 / 32];
 #pragma unroll
     for (int mt = 0; mt < kM1 / 32; ++mt)
@@ -79,7 +86,8 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
     for (int qt = 0; qt < kQ; ++qt) {
       if (qt + 1 < kQ) {
 #pragma unroll
-        for (int j = 0; j < kQSteps / 4; ++j) nxt[j] = src[(qt + 1) * (kQSteps / 4) + j];
+        for (int j = 0; j < kQSteps / 4; ++j)
+          nxt[j] = HEAD_AB(1) ? make_float4((float)lane, (float)qt, 2.f, (float)j) : src[(qt + 1) * (kQSteps / 4) + j];
       }
       const float* wq = A1 + (qt * kQSteps) * 64 + lane;
 #pragma unroll
@@ -87,8 +95,10 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
         const float4 v = cur[s >> 2];
         const float x = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
 #pragma unroll
-        for (int mt = 0; mt < kM1 / 32; ++mt)
-          c1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kS1 + s) * 64], x, c1[mt], 0, 0, 0);
+        for (int mt = 0; mt < kM1 / 32; ++mt) {
+          if (HEAD_AB(2)) c1[mt][s & 15] += wq[(mt * kS1 + s) * 64] * x;
+          else c1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(mt * kS1 + s) * 64], x, c1[mt], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int j = 0; j < kQSteps / 4; ++j) cur[j] = nxt[j];
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
         c2[mt][4 * g] = bias.x; c2[mt][4 * g + 1] = bias.y; c2[mt][4 * g + 2] = bias.z; c2[mt][4 * g + 3] = bias.w;
       }
 #pragma unroll
-    for (int s = 0; s < kS2; ++s) {
+    for (int s = 0; s < (HEAD_AB(4) ? 2 : kS2); ++s) {
       // every 8 steps the LDS offset is re-materialised behind the accumulators: keeps the scheduler from hoisting all
       // 96 weight reads of the layer to its top (which spills)
       if (s % 8 == 0) asm volatile("" : "+v"(a2_off), "+v"(c2[0]), "+v"(c2[1]));
@@ -120,13 +130,13 @@ __global__ __launch_bounds__(kHeadBlock) void point_head(HeadArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) c3[r] = 0.0f;
 #pragma unroll
-    for (int s = 0; s < kS3; ++s) {
+    for (int s = 0; s < (HEAD_AB(4) ? 2 : kS3); ++s) {
       if (s % 8 == 0) asm volatile("" : "+v"(a3_off), "+v"(c3));
       c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(A3[s * 64 + a3_off], fmaxf(c2[s >> 4][s & 15], 0.0f), c3, 0, 0, 0);
     }
 
     // row i of the result = 8 (r >> 2) + 4 h + (r & 3): lane half h, register r
-    if (valid) {
+    if (valid && !(HEAD_AB(8) && c3[0] != 12345.678f)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = 8 * (r >> 2) + 4 * hh + (r & 3);
