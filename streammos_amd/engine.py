@@ -560,7 +560,8 @@ class InferenceEngine:
         x1cat = ops.empty_cl(bs, 2 * c1, hb // 4, wb // 4, dev)
         # the four zero-initialised scatter-max targets of the frame's two cross-view transfers (two range-view maps, the upper
         # channel halves of the two concatenation buffers) in one launch instead of four torch fills
-        rv0, rv1 = ops.empty_cl(bs, c0, 32, 1024, dev), ops.empty_cl(bs, c1, 16, 512, dev)
+        hw0, hw1 = (32, 1024), (16, 512)               # range-view maps of the two cross-view transfers
+        rv0, rv1 = ops.empty_cl(bs, c0, hw0[0], hw0[1], dev), ops.empty_cl(bs, c1, hw1[0], hw1[1], dev)
         ops.zero_views_cl([rv0, x0cat[:, c0:], rv1, x1cat[:, c1:]])
         if self.sparse_stem and self.stem_w is not None:
             # sparse first stage: the occupancy of the grid follows from the coordinates alone, so the point MLP scatters
@@ -575,9 +576,9 @@ class InferenceEngine:
             ops.pointnet_scatter(point_feat.float(), pcds_coord, self.pp1[0], self.pp1[1], self.pp2[0], self.pp2[1], bev_cl,
                                  pts_out=fuse[:, :, :o1], zero_fill=True)
             self._stage_cl(bev_cl.permute(0, 3, 1, 2), self.header_bev, out=x0cat[:, :c0])
-        self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, (32, 1024), (0.5, 0.5), rv=rv0)
+        self._cross_view_cl(x0cat, c0, bev_xy, sphere, self.header_rv, hw0, (0.5, 0.5), rv=rv0)
         self._stage_cl(x0cat, self.res1_bev, out=x1cat[:, :c1])
-        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, (16, 512), (0.25, 0.25), point_rows=fuse[:, :, o2:], n_live=n_live,
+        self._cross_view_cl(x1cat, c1, bev_xy, sphere, self.res1_rv, hw1, (0.25, 0.25), point_rows=fuse[:, :, o2:], n_live=n_live,
                             rv=rv1)
         # res2 (the third BEV stage) is independent of the past too, but it runs in decode(): that keeps the two pipeline
         # stages balanced so both HIP streams stay busy (re-measured after the sparse first stage shortened the encoder:
