@@ -27,7 +27,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     """Compile every csrc/*.hip to an object (parallel) and link them into lib/libsmos_hip.so."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(PKG), "include", "smos.h")]
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(os.path.dirname(PKG), "include", "smos.h")]
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
