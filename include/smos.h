@@ -444,6 +444,20 @@ int smos_channel_gate_apply_cl(const float* y, int64_t y_pitch, const float* bia
                                const float* w2, const float* b2, const float* xres, int64_t res_pitch, float* out,
                                int64_t out_pitch, const float* chan_sums, int64_t chunks, float* gate_ws, int64_t B, int64_t C,
                                int64_t Cr, int64_t HW, smos_stream_t stream);
+/* EXPERIMENTAL (off by default in the engine): n_layers (2 .. 12) stride-1 3x3 convolutions C -> C of one map size -- the 2 k
+ * convolutions of k consecutive BasicBlocks (networks/backbone.py:136-159) -- as ONE launch of the Winograd kernel, every block
+ * computing its work item of layer 0, 1, .. in turn behind a per-region dataflow wait instead of a launch boundary
+ * (csrc/conv_wino_chain.hip).  Layer L reads x0 (L = 0) or outs[L - 1]; res_from[L]: -1 no residual, 0 = x0, j > 0 = outs[j - 1];
+ * acts[L] as smos_conv_wino_cl; wprep[L] = ops.conv_wino_prepare(w, mb); chan_sums: channel sums of the last layer (or NULL).
+ * Every layer needs its own output map.  ws: smos_conv_wino_chain_ws_ints int32 words, zeroed once; launch_no = 1, 2, .. counts
+ * the launches that used this ws with these sizes; ws[last] != 0 afterwards = a wait gave up, results invalid.  C % (16 mb) == 0 and
+ * B * ceil(H/8) * ceil(W/32) * C/(16 mb) <= resident blocks (else SMOS_ERR_ARG: use the launch-by-launch form).  Results equal the
+ * separate smos_conv_wino_cl launches bit for bit. */
+int64_t smos_conv_wino_chain_ws_ints(int64_t n_layers, int64_t B, int64_t H, int64_t W);
+int smos_conv_wino_chain_cl(int32_t n_layers, const float* x0, int64_t x0_pitch, const float* const* wprep, const float* const* bias,
+                            const int32_t* res_from, float* const* outs, const int64_t* out_pitches, const int32_t* acts,
+                            float* chan_sums, int32_t* ws, int32_t launch_no, int64_t B, int64_t H, int64_t W, int64_t C,
+                            int32_t mb, smos_stream_t stream);
 /* BasicBlock.forward (networks/backbone.py:136-159: conv3x3-BN-ReLU, conv3x3-BN, optional ChannelAtt gate, + x, ReLU) on
  * channels-last maps as ONE foreign call: enqueues smos_conv_wino_cl twice (+ smos_channel_gate_apply_cl when gw1 != NULL) on
  * `stream` -- the same launches with the same arguments as the separate calls, so results are bit-identical; what is saved is

@@ -56,6 +56,9 @@ SIGNATURES = {
     "smos_basic_block_cl": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp],
     "smos_unbalance_block_cl": [vp, i64, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp],
     "smos_zero_views_cl": [i32, ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],
+    "smos_conv_wino_chain_ws_ints": [i64, i64, i64, i64],
+    "smos_conv_wino_chain_cl": [i32, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(vp), c_i64p,
+                                ctypes.POINTER(i32), vp, vp, i32, i64, i64, i64, i64, i32, vp],
     "smos_msda_fwd_qp": [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
     "smos_add_layer_norm": [vp, vp, vp, vp, vp, i64, i64, ctypes.c_float, vp],
     "smos_tfusion_project": [i32, ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p, vp],
@@ -113,6 +116,7 @@ def load():
     lib.smos_conv_cl_sum_chunks.restype = ctypes.c_int64
     lib.smos_conv_wino_sum_chunks.restype = ctypes.c_int64
     lib.smos_basic_block_ws_floats.restype = ctypes.c_int64
+    lib.smos_conv_wino_chain_ws_ints.restype = ctypes.c_int64
     lib.smos_point_head_weight_floats.restype = ctypes.c_int64
     lib.smos_tfusion_layer_param_floats.restype = ctypes.c_int64
     lib.smos_tfusion_layer_stream_floats.restype = ctypes.c_int64

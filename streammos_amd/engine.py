@@ -173,6 +173,7 @@ class InferenceEngine:
         self.wino1d = os.environ.get("SMOS_WINO1D", "1") != "0"  # 1-D Winograd F(2,3) for the k x 3 / 3 x k layers (A/B switch)
         self.pool_fused = os.environ.get("SMOS_POOL_FUSED", "1") != "0"   # DownSample2D pool branch + tail in one launch (A/B switch)
         self.block_call = os.environ.get("SMOS_BLOCK_CALL", "1") != "0"   # BasicBlock = one foreign call (A/B switch; same launches)
+        self.wino_chain = os.environ.get("SMOS_WINO_CHAIN", "0") == "1"   # EXPERIMENTAL: runs of BasicBlocks as one dataflow launch
         self._wprep = {}
         self._wino_plan = {}
         self._shapes = None
@@ -522,9 +523,69 @@ class InferenceEngine:
                                             out=out if out is not None else y2)
 
     def _stage_cl(self, x, blocks, out=None):
-        for i, p in enumerate(blocks):
-            x = self._block_cl(x, p, out if i == len(blocks) - 1 else None)
+        i = 0
+        while i < len(blocks):
+            run = self._chain_run(x, blocks, i) if self.wino_chain else 0
+            if run >= 2:
+                x = self._chain_cl(x, blocks[i:i + run], out if i + run == len(blocks) else None)
+                i += run
+                continue
+            x = self._block_cl(x, blocks[i], out if i == len(blocks) - 1 else None)
+            i += 1
         return x
+
+    # ---- EXPERIMENTAL (SMOS_WINO_CHAIN=1): consecutive BasicBlocks of a stage as one launch (csrc/conv_wino_chain.hip) ----
+    def _chain_run(self, x, blocks, i):
+        """Number of consecutive BasicBlocks from blocks[i] on that one smos_conv_wino_chain_cl launch can take: mb = 2, at most
+        one work item per CU (where a launch-by-launch layer leaves half of every CU idle anyway), at most 12 layers, a gated
+        block only at the end, no profiling (labels are per launch) and no graph capture (the launch counter is host state)."""
+        if not (self.own_conv and self.wino and self.fused_gate_sums) or profiling.enabled() or torch.cuda.is_current_stream_capturing():
+            return 0
+        b, c, h, w = x.shape
+        if c % 32 or b * ((h + 7) // 8) * ((w + 31) // 32) * (c // 32) > 256 or x.numel() > (1 << 26):
+            return 0
+        n = 0
+        while i + n < len(blocks) and n < 6:
+            p = blocks[i + n]
+            if p.kind != "basic" or tuple(p.w1.shape) != (c, c, 3, 3) or tuple(p.w2.shape) != (c, c, 3, 3):
+                break
+            if p.att and not ops.basic_block_ok(c, True):
+                break
+            n += 1
+            if p.att:
+                break
+        return n
+
+    def _chain_cl(self, x, blocks, out=None):
+        b, c, h, w = x.shape
+        dev = x.device
+        layers, last = [], blocks[-1]
+        for k, p in enumerate(blocks):
+            plan = p.__dict__.get("plan")
+            if not plan:
+                plan = p.__dict__["plan"] = ops.BasicBlockPlan(p.w1, p.b1, p.w2, p.b2, (p.cw1, p.cb1, p.cw2, p.cb2) if p.att else None)
+            u1, b1, u2, b2, _ = plan._keep
+            layers.append((u1, b1, -1, ops.empty_cl(b, c, h, w, dev), RELU))
+            dst = out if (out is not None and k == len(blocks) - 1) else ops.empty_cl(b, c, h, w, dev)
+            if p.att:
+                layers.append((u2, None, -1, dst, NONE))
+            else:
+                layers.append((u2, b2, 2 * k, dst, RELU))
+        key = (ops._raw_stream(ops._dev_index(self.device)), ops._ws_namespace, len(layers), b, h, w)
+        table = last.__dict__.setdefault("chain_ws", {})
+        cw = table.get(key)
+        if cw is None:
+            cw = table[key] = ops.WinoChainWorkspace(len(layers), b, h, w, dev)
+        sums = ws = None
+        if last.att:
+            chunks = ops.conv_wino_sum_chunks(h, w)
+            ws = self._block_ws(last, b * c * (chunks + 1))
+            sums = ws[:b * chunks * c].view(b, chunks, c)
+        y = ops.conv_wino_chain_cl(x, layers, cw, chan_sums=sums)
+        if last.att:
+            res = layers[-3][3] if len(layers) >= 3 else x            # the gated block's input = the previous block's output
+            return ops.channel_gate_apply_cl(y, last.b2, last.cw1, last.cb1, last.cw2, last.cb2, res, sums, ws[b * chunks * c:], out=y)
+        return y
 
     def _cross_view_cl(self, cat_buf, c, bev_xy, sphere, rv_blocks, rv_hw, scale, point_rows=None, n_live=None, rv=None):
         """B2P gather + P2R scatter, range-view convs, R2P gather + P2B scatter straight into cat_buf[:, c:]

@@ -727,6 +727,54 @@ def conv_wino_cl(x, wprep, bias, act, cout, mb=2, residual=None, out=None, chan_
     return out
 
 
+class WinoChainWorkspace:
+    """Completion counters of smos_conv_wino_chain_cl for one (layer count, map shape): zeroed once, then monotonic -- launch k
+    waits for k * nct -- so nothing is cleared between launches.  One per call site AND stream (two launches that share it
+    must not overlap)."""
+
+    def __init__(self, n_layers, b, h, w, device):
+        lib = _lib.load()
+        self.key = (n_layers, b, h, w)
+        self.ws = torch.zeros(lib.smos_conv_wino_chain_ws_ints(n_layers, b, h, w), dtype=torch.int32, device=device)
+        self.launch_no = 0
+
+    def gave_up(self):
+        """True if a wait of any launch so far ran out of polls (the results of that launch are invalid).  Synchronises."""
+        return bool(self.ws[-1].item())
+
+
+def conv_wino_chain_cl(x, layers, chain_ws, chan_sums=None, mb=2):
+    """EXPERIMENTAL.  A run of stride-1 3x3 convolutions C -> C of one map size in ONE launch (csrc/conv_wino_chain.hip): layer L
+    reads x (L = 0) or layer L - 1's output.  layers: list of (wprep = conv_wino_prepare(w, mb), bias or None, res_from, out, act)
+    with res_from -1 (none), 0 (= x) or j > 0 (= the output of layer j - 1); every `out` its own channels-last map of x's shape.
+    chan_sums: the channel-sum table of the LAST layer (as conv_wino_cl's).  Bit-identical to the conv_wino_cl launches."""
+    n = len(layers)
+    b, c, h, w = x.shape
+    if chain_ws.key != (n, b, h, w) or chain_ws.ws.device != x.device:
+        raise RuntimeError("conv_wino_chain_cl: workspace made for %s, called with %s" % (chain_ws.key, (n, b, h, w)))
+    _require_cuda("conv_wino_chain_cl", x, chan_sums, *[t for l in layers for t in (l[0], l[1], l[3])])
+    wp, bs, outs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    rf, acts, pit = (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)()
+    for i, (wprep, bias, res_from, out, act) in enumerate(layers):
+        if wprep.numel() != 16 * c * c or tuple(out.shape) != (b, c, h, w):
+            raise RuntimeError("conv_wino_chain_cl: layer %d: weight block or output of the wrong size" % i)
+        wp[i], bs[i], outs[i] = wprep.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr()
+        rf[i], acts[i], pit[i] = int(res_from), int(act), _cl("conv_wino_chain_cl", out)
+    if chan_sums is not None and (not chan_sums.is_contiguous() or chan_sums.dtype != torch.float32 or
+                                  tuple(chan_sums.shape) != (b, conv_wino_sum_chunks(h, w), c)):
+        raise RuntimeError("conv_wino_chain_cl: chan_sums must be contiguous float32 [B, conv_wino_sum_chunks(H, W), C]")
+    chain_ws.launch_no += 1
+    dev = x.device
+    with _on(dev):
+        rc = _lib.load().smos_conv_wino_chain_cl(n, x.data_ptr(), _cl("conv_wino_chain_cl", x), wp, bs, rf, outs, pit, acts,
+                                                 chan_sums.data_ptr() if chan_sums is not None else None, chain_ws.ws.data_ptr(),
+                                                 chain_ws.launch_no, b, h, w, c, int(mb), _raw_stream(_dev_index(dev)))
+    if rc:
+        chain_ws.launch_no -= 1
+        _lib.check(rc, "smos_conv_wino_chain_cl")
+    return layers[-1][3]
+
+
 class BasicBlockPlan:
     """Operands of one BasicBlock (networks/backbone.py:136-159) for smos_basic_block_cl: the two Winograd weight blocks, the
     biases and, for a ChannelAtt block, the gate MLP -- device addresses taken once (the tensors are kept alive here)."""

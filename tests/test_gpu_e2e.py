@@ -196,6 +196,35 @@ def test_block_call_is_bit_identical(model):
         assert torch.equal(p0, p1) and torch.equal(m0, m1)
 
 
+def test_wino_chain_is_bit_identical(model):
+    """EXPERIMENTAL switch SMOS_WINO_CHAIN (engine.wino_chain): the consecutive BasicBlocks of the third BEV stage and of the
+    64-channel range-view stage as ONE dataflow launch each (csrc/conv_wino_chain.hip) against the default launches: logits and
+    recurrent memory equal bit for bit over three streamed frames; no wait of any launch gave up."""
+    frames = list(cases.e2e_frames(3))
+    model.fast_inference, model.engine_layout = True, "cl"
+    with torch.no_grad():
+        eng = model._engine_for(torch.zeros(1, device=DEV))
+    assert not eng.wino_chain                               # off by default
+    outs = []
+    try:
+        for on in (True, False):
+            eng.wino_chain = on
+            memory, res = None, []
+            with torch.no_grad():
+                for i, batch in enumerate(frames):
+                    tb = {k: torch.from_numpy(v).unsqueeze(0).to(DEV) for k, v in batch.items()}
+                    pred, a0, a1, a2, memory = model.infer(tb, i, memory)
+                    res.append((pred.clone(), memory.clone()))
+            outs.append(res)
+    finally:
+        eng.wino_chain = False
+    tables = [p.__dict__.get("chain_ws") for stage in (eng.header_bev, eng.header_rv, eng.res1_bev, eng.res1_rv, eng.res2) for p in stage]
+    used = [cw for t in tables if t for cw in t.values()]
+    assert used and all(cw.launch_no >= 3 for cw in used) and not any(cw.gave_up() for cw in used)
+    for (p0, m0), (p1, m1) in zip(*outs):
+        assert torch.equal(p0, p1) and torch.equal(m0, m1)
+
+
 @pytest.mark.parametrize("fill", ["lidar", "empty_sample", "dense_corner"])
 def test_sparse_stem_equals_dense_downsample(model, fill):
     """header_bev[0] computed on the occupied cells only (stem_mark + per-parity-class GEMMs + stem_epilogue) against

@@ -1201,6 +1201,50 @@ def test_unbalance_block_cl_equals_the_separate_launches(c, hw, k):
         ops.unbalance_block_cl(x, plan, both=ops.empty_cl(b, c, h, w, DEV))      # `both` too narrow
 
 
+@pytest.mark.parametrize("c,hw,b,n_blocks,gated", [(128, (64, 64), 4, 5, True), (64, (16, 64), 2, 2, False), (32, (8, 32), 1, 3, True)])
+def test_conv_wino_chain_cl_equals_the_separate_launches(c, hw, b, n_blocks, gated):
+    """EXPERIMENTAL smos_conv_wino_chain_cl: the 2 k convolutions of k BasicBlocks in one launch with per-region dataflow waits,
+    against the same convolutions launch by launch (conv_wino_cl): bit for bit, on three launches in a row that share the
+    workspace (its counters are monotonic), with the last block's conv leaving its channel sums; the workspace never reports
+    a wait that gave up.  (128 ch @64^2 x 4 = the third BEV stage: 256 work items, one per CU.)"""
+    gen = torch.Generator(device="cpu").manual_seed(307)
+    h, w = hw
+    ws = ops.WinoChainWorkspace(2 * n_blocks, b, h, w, DEV)
+    wts = [((torch.randn((c, c, 3, 3), generator=gen) * (1.0 / (c * 9)) ** 0.5).to(DEV), (torch.randn(c, generator=gen) * 0.1).to(DEV))
+           for _ in range(2 * n_blocks)]
+    preps = [ops.conv_wino_prepare(wt, 2) for wt, _ in wts]
+    chunks = ops.conv_wino_sum_chunks(h, w)
+    for trial in range(3):
+        x = torch.randn((b, h, w, c), generator=gen).to(DEV).permute(0, 3, 1, 2)
+        # launch by launch
+        cur, want_sums = x, None
+        for k in range(n_blocks):
+            y = ops.conv_wino_cl(cur, preps[2 * k], wts[2 * k][1], ops.ACT_RELU, c, mb=2)
+            if gated and k == n_blocks - 1:
+                want_sums = torch.empty((b, chunks, c), device=DEV)
+                cur = ops.conv_wino_cl(y, preps[2 * k + 1], None, ops.ACT_NONE, c, mb=2, chan_sums=want_sums)
+            else:
+                cur = ops.conv_wino_cl(y, preps[2 * k + 1], wts[2 * k + 1][1], ops.ACT_RELU, c, mb=2, residual=cur)
+        want = cur
+        # one launch
+        layers, sums = [], None
+        for k in range(n_blocks):
+            layers.append((preps[2 * k], wts[2 * k][1], -1, ops.empty_cl(b, c, h, w, DEV), ops.ACT_RELU))
+            if gated and k == n_blocks - 1:
+                sums = torch.full((b, chunks, c), 3.0, device=DEV)
+                layers.append((preps[2 * k + 1], None, -1, ops.empty_cl(b, c, h, w, DEV), ops.ACT_NONE))
+            else:
+                layers.append((preps[2 * k + 1], wts[2 * k + 1][1], 2 * k, ops.empty_cl(b, c, h, w, DEV), ops.ACT_RELU))
+        got = ops.conv_wino_chain_cl(x, layers, ws, chan_sums=sums)
+        assert torch.equal(got, want), "trial %d" % trial
+        if gated:
+            assert torch.equal(sums, want_sums)
+    assert ws.launch_no == 3 and not ws.gave_up()
+    with pytest.raises(RuntimeError):                                   # two layers may not share an output map
+        shared = ops.empty_cl(b, c, h, w, DEV)
+        ops.conv_wino_chain_cl(x, [(preps[0], None, -1, shared, 0), (preps[1], None, -1, shared, 0)] + layers[2:], ws)
+
+
 def _tf_layer_weights(gen, ffn, nq):
     def lin(o, i):
         return ((torch.randn((o, i), generator=gen) / i ** 0.5).to(DEV), (torch.randn(o, generator=gen) * 0.3).to(DEV))
