@@ -954,19 +954,22 @@ def main():
         if world == 1 and args.streams > 1:
             # configs[2]: S concurrent sequences advanced in lock step as one batch of 4*S samples
             S = args.streams
-            ms = streaming.MultiStreamRunner(model, device, n_streams=S, vote=not args.no_vote)
+            ms = streaming.MultiStreamRunner(model, device, n_streams=S, vote=not args.no_vote, pipeline=not args.no_pipeline)
             per_stream = [make_frames(4, seq_seed=100 + q) for q in range(S)]
             batched = []
             for f in range(4):
                 devs = [runner.upload(per_stream[q][f][0], per_stream[q][f][1]) for q in range(S)]
                 batched.append((ms.batch_inputs(devs), [per_stream[q][f][2] for q in range(S)]))
+            def ms_step(i):
+                nxt = batched[(i + 1) % 4][0] if ms.pipeline else None      # the next batch's encoder beside this batch's decoder
+                return ms.step(*batched[i % 4], next_batched=nxt)
             for i in range(3):
-                ms.step(*batched[i % 4])
+                ms_step(i)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             n_it = 10
             for i in range(n_it):
-                ms.step(*batched[(3 + i) % 4])
+                ms_step(3 + i)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t2
             line["batched_streams"] = {"streams": S, "value": round(S * n_it / dt, 3), "unit": "scans/s",

@@ -545,13 +545,19 @@ class MultiStreamRunner:
     concurrent sequences on one GPU, every stream's recurrent memory and voting window resident in HBM).
     Streams never interact: the network is batch-independent, the TTA reduce and the voting run per stream."""
 
-    def __init__(self, model, device="cuda:0", n_streams=8, vote=True):
+    def __init__(self, model, device="cuda:0", n_streams=8, vote=True, pipeline=False):
+        """pipeline=True: as StreamRunner(pipeline=True) -- step(batched, poses, next_batched=...) runs the encoder of the NEXT batch
+        on a second HIP stream beside the decoder of the current one, and the three aux heads nobody reads are not computed.
+        Same kernels, same results as pipeline=False."""
         self.device = torch.device(device)
         self.model = model.to(self.device).eval()
         self.n = n_streams
         self.voters = [VoxelVoter(self.device) for _ in range(n_streams)] if vote else None
         self.memory = None
         self.frame = 0
+        self.pipeline = pipeline
+        self._side = concurrent_stream(self.device) if pipeline else None
+        self._pre_enc = None
 
     @staticmethod
     def batch_inputs(devs):
@@ -560,10 +566,37 @@ class MultiStreamRunner:
         out["streams"] = [{k: d[k] for k in d if k not in out} for d in devs]
         return out
 
+    _KEYS = ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")
+
+    def _pipelined(self, batched, next_batched):
+        eng = self.model._engine_for(batched["pcds_xyzi"])
+        if eng is None:
+            raise RuntimeError("MultiStreamRunner(pipeline=True) needs the fused GPU engine (eval mode, fast_inference)")
+        main = torch.cuda.current_stream(self.device)
+        if self._pre_enc is not None and self._pre_enc[0] is batched:
+            enc = self._pre_enc[1]
+            main.wait_stream(self._side)
+        else:
+            enc = eng.encode(*(batched[k] for k in self._KEYS))
+        self._pre_enc = None
+        if next_batched is not None:
+            self._side.wait_stream(main)          # behind whatever produced next_batched (batch_inputs runs on the main stream)
+            with torch.cuda.stream(self._side):
+                nxt = eng.encode(*(next_batched[k] for k in self._KEYS))
+            for t in list(nxt.values()) + [next_batched[k] for k in self._KEYS]:
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+                    t.record_stream(self._side)
+            self._pre_enc = (next_batched, nxt)
+        return eng.decode(enc, self.memory if self.frame > 0 else None, want_aux=False)
+
     @torch.no_grad()
-    def step(self, batched, poses):
-        batch = {k: batched[k].unsqueeze(0) for k in ("pcds_xyzi", "pcds_coord", "pcds_sphere_coord")}
-        res = self.model.infer(batch, self.frame, self.memory)
+    def step(self, batched, poses, next_batched=None):
+        if self.pipeline:
+            res = self._pipelined(batched, next_batched)
+        else:
+            batch = {k: batched[k].unsqueeze(0) for k in self._KEYS}
+            res = self.model.infer(batch, self.frame, self.memory)
         pred_cls, self.memory = res[0], res[-1]
         v = pred_cls.shape[0] // self.n
         outs = []

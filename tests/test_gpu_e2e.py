@@ -446,14 +446,20 @@ def test_concurrent_streams_equal_separate_streams(model):
             outs.append((o["pred_cls"].clone(), o["raw_labels"].clone()))
         solo.append(outs)
     ms = streaming.MultiStreamRunner(model, DEV, n_streams=2, vote=False)
+    msp = streaming.MultiStreamRunner(model, DEV, n_streams=2, vote=False, pipeline=True)      # two HIP streams, one batch of look-ahead
     up = streaming.StreamRunner(model, DEV, vote=False)
+    batches = []
     for i in range(3):
         devs = []
         for scans, poses in seqs:
             idx = preprocess.window_indices(i, 6, 3)
             sample = preprocess.build_sample([scans[j] for j in idx], [poses[j] for j in idx], 2048, spec, tta=True)
             devs.append(up.upload(sample, scans[i]))
-        pred, outs = ms.step(ms.batch_inputs(devs), [seqs[q][1][i] for q in range(2)])
+        batches.append(ms.batch_inputs(devs))
+    for i in range(3):
+        pred, outs = ms.step(batches[i], [seqs[q][1][i] for q in range(2)])
+        pred_p, outs_p = msp.step(batches[i], [seqs[q][1][i] for q in range(2)], next_batched=batches[i + 1] if i + 1 < 3 else None)
+        assert torch.equal(pred_p, pred) and all(torch.equal(a["raw_labels"], b["raw_labels"]) for a, b in zip(outs_p, outs))
         for q in range(2):
             want_pred, want_raw = solo[q][i]
             err = (pred[4 * q:4 * q + 4] - want_pred).abs().max().item() / want_pred.abs().max().item()
