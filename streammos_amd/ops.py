@@ -1123,10 +1123,10 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
     zs, ts = [], []
     pre = {}
     if _TAP_GEMM == "tf":
-        # the tap products of every source that has none yet, as jobs of ONE launch of the token-wise Linear kernel
-        # (a product matrix of 2 GiB and more -- 16 concurrent streams -- stays on the library GEMM: 32-bit buffer offsets)
-        todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048 and
-                src[0].shape[0] * src[0].shape[2] * src[0].shape[3] * 9 * src[1].cout * 4 < (1 << 31)]
+        # the tap products of every source that has none yet, as jobs of the token-wise Linear kernel: one launch for the usual
+        # sizes; a product matrix of 2 GiB and more (8 and more concurrent streams) is cut into row ranges below 2 GiB (a job
+        # addresses its operands with 32-bit buffer offsets) and takes as many launches of up to 8 jobs as that needs
+        todo = [i for i, src in enumerate(sources) if (len(src) < 3 or src[2] is None) and src[0].shape[1] == 128 and 9 * src[1].cout <= 2048]
         if todo:
             # every source's outputs in `parts` column ranges = parts x len(todo) jobs of 64-token blocks:
             # column ranges shorten the last, partly empty round of resident blocks (tools/ubench_taps.py: 0.230 / 0.213 / 0.211 ms for 1 / 2 / 3 ranges; library GEMMs 0.278)
@@ -1138,9 +1138,13 @@ def upconv3x3(conv_a, bias, sources, act, out=None):
                 z = torch.empty((rows.shape[0], 9 * wt.cout), dtype=torch.float32, device=x.device)
                 pre[i] = z
                 n = 9 * wt.cout // parts
-                for k, ws_k in enumerate(wt.stream(parts)):
-                    jobs.append((rows, ws_k, n, z[:, k * n:(k + 1) * n]))
-            tfusion_project(jobs)
+                limit = ((1 << 31) - 4096) // (9 * wt.cout * 4) // 64 * 64          # rows whose z (and x) slice stays below 2 GiB
+                for r0 in range(0, rows.shape[0], limit):
+                    r1 = min(r0 + limit, rows.shape[0])
+                    for k, ws_k in enumerate(wt.stream(parts)):
+                        jobs.append((rows[r0:r1], ws_k, n, z[r0:r1, k * n:(k + 1) * n]))
+            for j0 in range(0, len(jobs), 8):
+                tfusion_project(jobs[j0:j0 + 8])
     with _on(conv_a.device):
         for i_src, src in enumerate(sources):
             x, wt = src[0], src[1]
